@@ -1,0 +1,127 @@
+"""ctypes binding of libgunet_hip.so (the C ABI declared in include/gunet_hip.h).
+
+The library is the only compute path: if it is missing, importing this module
+raises, and nothing falls back to PyTorch or to a CPU implementation.  PyTorch
+is used by the callers for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgunet_hip.so')
+
+ACT_LINEAR = 0
+ACT_RELU = 1
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+
+
+class GunetError(RuntimeError):
+    """A libgunet_hip entry point returned a non-zero status."""
+
+    def __init__(self, fn, code, message):
+        super().__init__(f'{fn} failed with status {code}: {message}')
+        self.code = code
+
+
+class QuadGraphStruct(C.Structure):
+    _fields_ = [('n_nodes', C.c_int32),
+                ('n_edges', C.c_int32 * 4),
+                ('edge_index', C.c_void_p * 4),
+                ('rowptr', C.c_void_p * 4),
+                ('perm', C.c_void_p * 4)]
+
+
+class GnWeightsStruct(C.Structure):
+    _fields_ = [('c_in', C.c_int32), ('f_e', C.c_int32), ('g', C.c_int32), ('units', C.c_int32),
+                ('node_emb_w', C.c_void_p * 4), ('node_emb_b', C.c_void_p * 4),
+                ('edge_w', C.c_void_p * 4), ('edge_b', C.c_void_p * 4),
+                ('glob_w', C.c_void_p * 4), ('glob_b', C.c_void_p * 4),
+                ('node_w', C.c_void_p), ('node_b', C.c_void_p),
+                ('globt_w', C.c_void_p), ('globt_b', C.c_void_p),
+                ('global_scale_nodes', C.c_float), ('global_scale_edges', C.c_float)]
+
+
+VoidP4 = C.c_void_p * 4
+I64x4 = C.c_int64 * 4
+
+# name -> (restype, argtypes); every symbol declared in include/gunet_hip.h
+SIGNATURES = {
+    'gunet_last_error': (C.c_char_p, []),
+    'gunet_version': (C.c_int, []),
+    'gunet_quadrant_partition': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(VoidP4),
+                                           C.POINTER(I64x4), C.c_void_p]),
+    'gunet_csr_build': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    'gunet_csr_from_keys': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    'gunet_cluster_ids': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_int64), C.c_void_p]),
+    'gunet_pool_edges': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    'gunet_upsample_edges': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.POINTER(VoidP4), C.POINTER(I64x4), C.c_void_p]),
+    'gunet_get_sender_receiver_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'gunet_segment_max_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    'gunet_segment_sum_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    'gunet_dense_forward_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'gunet_gn_layer_workspace_bytes': (C.c_size_t, [C.POINTER(QuadGraphStruct), C.c_int32,
+                                                    C.c_int32]),
+    'gunet_gn_layer_forward_f32': (C.c_int, [C.POINTER(QuadGraphStruct),
+                                             C.POINTER(GnWeightsStruct), C.c_int32, C.c_void_p,
+                                             C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_void_p,
+                                             C.POINTER(VoidP4), C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, "csrc")}` '
+            '(or python -c "import __graft_entry__ as g; g.build()"); there is no fallback path')
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.gunet_last_error().decode('utf-8', 'replace')
+
+
+def check(fn_name, status):
+    if status != 0:
+        raise GunetError(fn_name, status, last_error())
+
+
+def call(fn_name, *args):
+    """Call a status-returning entry point and raise GunetError on failure."""
+    check(fn_name, getattr(lib, fn_name)(*args))
+
+
+def ptr(t):
+    """Device address of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr4(tensors):
+    return VoidP4(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,81 @@
+// Shared helpers of libgunet_hip.so: error reporting, launch checks, RAII device scratch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "gunet_hip.h"
+
+namespace gunet {
+
+void set_error(const char* fmt, ...);
+
+#define GUNET_HIP_TRY(expr)                                                              \
+  do {                                                                                   \
+    hipError_t err_ = (expr);                                                            \
+    if (err_ != hipSuccess) {                                                            \
+      ::gunet::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                   \
+                         hipGetErrorString(err_));                                       \
+      return GUNET_ERR_HIP;                                                              \
+    }                                                                                    \
+  } while (0)
+
+#define GUNET_LAUNCH_CHECK() GUNET_HIP_TRY(hipGetLastError())
+
+#define GUNET_REQUIRE(cond, ...)                                                         \
+  do {                                                                                   \
+    if (!(cond)) {                                                                       \
+      ::gunet::set_error(__VA_ARGS__);                                                   \
+      return GUNET_ERR_INVALID;                                                          \
+    }                                                                                    \
+  } while (0)
+
+#define GUNET_TRY(expr)                                                                  \
+  do {                                                                                   \
+    int rc_ = (expr);                                                                    \
+    if (rc_ != GUNET_OK) return rc_;                                                     \
+  } while (0)
+
+// Temporary device allocation owned by a plan function (freed on scope exit).
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() {
+    if (ptr_) (void)hipFree(ptr_);
+  }
+  hipError_t alloc(size_t bytes) {
+    if (ptr_) {
+      (void)hipFree(ptr_);
+      ptr_ = nullptr;
+    }
+    if (bytes == 0) bytes = 16;
+    return hipMalloc(&ptr_, bytes);
+  }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(ptr_);
+  }
+
+ private:
+  void* ptr_ = nullptr;
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline hipStream_t as_stream(gunet_stream_t s) { return static_cast<hipStream_t>(s); }
+
+// Exclusive prefix sum of `n` int32 values into out[0..n] (n + 1 entries; out[n] = total).
+// `in` and `out` may not alias.  Allocates its own block-sum scratch.
+int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, hipStream_t stream);
+
+// Segments from keys: rowptr[n_segments + 1], perm = members of each segment ascending.
+// keys[i * key_stride + key_offset] is the key of element i; negative keys are skipped.
+int csr_from_keys(const int32_t* keys, int key_stride, int key_offset, int64_t n,
+                  int32_t n_segments, int32_t* rowptr, int32_t* perm, hipStream_t stream);
+
+}  // namespace gunet

@@ -1,0 +1,175 @@
+/*
+ * libgunet_hip.so -- C ABI of the MI355X (gfx950) Graph U-Net forward path.
+ *
+ * Every entry point is extern "C", takes plain device pointers and sizes, never
+ * throws and never owns caller memory.  Return value: 0 = ok, negative = error
+ * (GUNET_ERR_*); gunet_last_error() returns a thread-local message.
+ *
+ * The reference (LucaHermes/graph-unet-traffic-prediction) is pure Python on
+ * TensorFlow and has no FFI layer; each entry point below cites the Python
+ * function (file:line in the reference checkout) whose work it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - index-building entry points ("plan" functions: everything in section 1)
+ *     synchronise the stream and allocate temporary device memory internally;
+ *     feature entry points (section 2) are asynchronous, allocate nothing and
+ *     use only the workspace the caller hands in;
+ *   - feature tensors are row-major float32 with a leading batch dimension B of
+ *     independent samples that share one graph: x [B,N,C], edges [B,E_q,F],
+ *     global [B,G].  B = 1 reproduces the reference's single-sample call.
+ */
+#ifndef GUNET_HIP_H
+#define GUNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GUNET_OK 0
+#define GUNET_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, index out of range) */
+#define GUNET_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define GUNET_ERR_WORKSPACE (-3)   /* workspace too small */
+#define GUNET_ERR_UNSUPPORTED (-4) /* configuration the library does not implement */
+
+#define GUNET_ACT_LINEAR 0
+#define GUNET_ACT_RELU 1
+
+typedef void* gunet_stream_t;
+
+const char* gunet_last_error(void);
+int gunet_version(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Index ("plan") functions -- integer work, bit-exact with the reference
+ * ------------------------------------------------------------------------ */
+
+/* data/data_utils.py:47-58 sample_quadrant_subgraphs (with QUADRANT_IDS :24-30).
+ * Stable partition of the edge list into the NE, SE, SW, NW quadrant lists;
+ * directions 0,2,4,6 go to two lists, direction 8 (self-loop) to none.
+ * out_edges[q] must each hold n_edges rows of int32[2]; the number of rows
+ * written to each is returned in counts_host[q]. */
+int gunet_quadrant_partition(const int32_t* edge_index, const int64_t* direction, int64_t n_edges,
+                             int32_t* const out_edges[4], int64_t counts_host[4],
+                             gunet_stream_t stream);
+
+/* Receiver-sorted CSR of one quadrant edge list: the index structure behind
+ * tf.math.unsorted_segment_sum(edge, e_index[:,1], n_nodes)
+ * (layers/hybrid_gnn.py:110-111).  rowptr[n_nodes+1]; perm[n_edges] maps a CSR
+ * slot to the edge's position in the reference-ordered list, ascending inside a
+ * row, so a front-to-back walk adds messages in the reference's edge order. */
+int gunet_csr_build(const int32_t* edge_index, int64_t n_edges, int32_t n_nodes,
+                    int32_t* rowptr, int32_t* perm, gunet_stream_t stream);
+
+/* Generic form of the above: segments from an int32 key per element
+ * (key < 0 = element belongs to no segment).  rowptr[n_segments+1];
+ * perm[<= n] lists the elements of each segment in ascending order. */
+int gunet_csr_from_keys(const int32_t* keys, int64_t n, int32_t n_segments,
+                        int32_t* rowptr, int32_t* perm, gunet_stream_t stream);
+
+/* layers/hybrid_gnn.py:415-429 (graph_pooling_2x2, node part) and :270-280
+ * (GraphUpsampling2x2.call).  cluster[i] = tf.unique((row//2)*(max_row+1) +
+ * col//2).idx, i.e. the rank of the first occurrence of node i's 2x2 cell;
+ * pooled_loc = unsorted_segment_min(node_loc // 2) (may be NULL to skip).
+ * cluster[n_nodes]; pooled_loc holds up to n_nodes rows of int64[2]. */
+int gunet_cluster_ids(const int64_t* node_loc, int64_t n_nodes, int32_t* cluster,
+                      int64_t* pooled_loc, int64_t* n_pooled_host, gunet_stream_t stream);
+
+/* layers/hybrid_gnn.py:431-434 (transform_edges) + :391-408
+ * (remove_duplicate_edges), index part: relabel through `cluster`, drop
+ * duplicates keeping first occurrences (key = s*n_pre + r in int64), then drop
+ * self-loops.  new_edges holds up to n_edges rows; dup_map[e] is the row of
+ * edge e in new_edges, or -1 when it became a self-loop. */
+int gunet_pool_edges(const int32_t* edge_index, int64_t n_edges, const int32_t* cluster,
+                     int64_t n_pre, int32_t* new_edges, int32_t* dup_map,
+                     int64_t* n_new_host, gunet_stream_t stream);
+
+/* layers/hybrid_gnn.py:336-357 (GraphUpsampling2x2.call, method 'graph'):
+ * parent[i] = cluster id of fine node i, edge i = (parent[i], n_coarse + i),
+ * split into 4 lists by the child's place in its 2x2 cell
+ * (row even/col odd -> 0, odd/odd -> 1, odd/even -> 2, even/even -> 3).
+ * out_edges[q] must each hold n_fine rows. */
+int gunet_upsample_edges(const int64_t* coarse_loc, int64_t n_coarse, const int64_t* fine_loc,
+                         int64_t n_fine, int32_t* parent, int32_t* const out_edges[4],
+                         int64_t counts_host[4], gunet_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 2. Feature functions -- float32, asynchronous on `stream`
+ * ------------------------------------------------------------------------ */
+
+/* layers/graph_ops.py:5-17 get_sender_receiver: two row gathers.
+ * x [n_nodes, width]; senders/receivers [n_edges, width]. */
+int gunet_get_sender_receiver_f32(const float* x, int64_t n_nodes, int32_t width,
+                                  const int32_t* edge_index, int64_t n_edges, float* senders,
+                                  float* receivers, gunet_stream_t stream);
+
+/* tf.math.unsorted_segment_max / _sum over rows (layers/hybrid_gnn.py:401,427,
+ * 110).  src [B, n_src, width]; out [B, n_segments, width]; segments given as
+ * CSR (rowptr, perm) from gunet_csr_from_keys.  Empty segment: -FLT_MAX (max)
+ * or 0 (sum).  The sum adds rows front to back and multiplies by `scale`. */
+int gunet_segment_max_f32(const float* src, int64_t n_src, int32_t width, const int32_t* rowptr,
+                          const int32_t* perm, int64_t n_segments, int32_t batch, float* out,
+                          gunet_stream_t stream);
+int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const int32_t* rowptr,
+                          const int32_t* perm, int64_t n_segments, int32_t batch, float scale,
+                          float* out, gunet_stream_t stream);
+
+/* tf.keras.layers.Dense (models/graph_unet.py:37,58,66,82): out = act(x @ kernel + bias).
+ * x [rows, k]; kernel [k, n_out]; bias [n_out] or NULL; out [rows, n_out]. */
+int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float* kernel,
+                            const float* bias, int32_t n_out, int32_t activation, float* out,
+                            gunet_stream_t stream);
+
+/* One quadrant graph: 4 reference-ordered edge lists and their receiver CSRs. */
+typedef struct gunet_quadgraph {
+  int32_t n_nodes;
+  int32_t n_edges[4];
+  const int32_t* edge_index[4]; /* [E_q, 2] sender, receiver */
+  const int32_t* rowptr[4];     /* [n_nodes + 1] */
+  const int32_t* perm[4];       /* [E_q] */
+} gunet_quadgraph;
+
+/* Parameters of one GeoQuadrantGCN (layers/hybrid_gnn.py:20-70), in the layout
+ * of the reference's checkpoint: Dense kernels [in, out] row-major, one set per
+ * direction.  u = units / 4.  bias pointers may be NULL (use_bias=False).
+ * globt_w == NULL selects the identity global transform of the last layer. */
+typedef struct gunet_gn_weights {
+  int32_t c_in, f_e, g, units;
+  const float* node_emb_w[4]; /* [c_in, u] */
+  const float* node_emb_b[4]; /* [u] */
+  const float* edge_w[4];     /* [f_e + 3u, u] */
+  const float* edge_b[4];     /* [u] */
+  const float* glob_w[4];     /* [g, u] for q = 0, [u, u] for q = 1..3 */
+  const float* glob_b[4];     /* [u] */
+  const float* node_w;        /* [c_in + units + g, units] */
+  const float* node_b;        /* [units] */
+  const float* globt_w;       /* [g + units + u, units] or NULL */
+  const float* globt_b;       /* [units] or NULL */
+  float global_scale_nodes;
+  float global_scale_edges;
+} gunet_gn_weights;
+
+size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batch, int32_t units);
+
+/* layers/hybrid_gnn.py:72-137 GeoQuadrantGCN.call_concat with use_global=True.
+ *   x          [B, N, c_in]
+ *   edges[q]   [B, E_q, f_e], or NULL meaning all-zero edge features
+ *   global_in  [B, g]
+ *   x_out      [B, N, units]
+ *   edges_out[q] [B, E_q, u]          (graph['edges'] after the call)
+ *   global_out [B, units], or [B, g + units + u] when globt_w == NULL
+ * Only units == 128 is implemented. */
+int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* weights,
+                               int32_t batch, const float* x, const float* const edges[4],
+                               const float* global_in, int32_t activation, float* x_out,
+                               float* const edges_out[4], float* global_out, void* workspace,
+                               size_t workspace_bytes, gunet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUNET_HIP_H */

@@ -75,7 +75,17 @@ def _segment_reduce(ufunc, data, ids, num_segments, empty):
 
 
 def unsorted_segment_sum(data, ids, num_segments):
-    return _segment_reduce(np.add, data, ids, num_segments, 0)
+    """Rows are added in input order, one rank-within-segment at a time (each pass touches every
+    segment at most once, so the vectorised add is exactly the sequential sum)."""
+    data = np.asarray(data)
+    out = np.zeros((num_segments,) + data.shape[1:], dtype=data.dtype)
+    if data.shape[0] == 0 or num_segments == 0:
+        return out
+    order, counts, starts = _segments(ids, num_segments)
+    for r in range(int(counts.max())):
+        seg = np.nonzero(counts > r)[0]
+        out[seg] = out[seg] + data[order[starts[seg] + r]]
+    return out
 
 
 def unsorted_segment_max(data, ids, num_segments):

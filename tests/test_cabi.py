@@ -1,0 +1,45 @@
+"""The C-ABI library loads and exports every symbol include/gunet_hip.h declares (no GPU needed),
+and the host-side mirror keeps the reference's names."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, 'include', 'gunet_hip.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(gunet_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_declared_symbols():
+    import gunet_amd
+    lib = ctypes.CDLL(gunet_amd.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(lib, name), name
+    assert set(names) == set(gunet_amd._lib.SIGNATURES), 'ctypes table and header disagree'
+    assert gunet_amd._lib.lib.gunet_version() >= 1
+    assert gunet_amd._lib.last_error() == ''
+
+
+def test_mirror_keeps_reference_names():
+    import gunet_amd
+    from gunet_amd.layers import hybrid_gnn, graph_ops, get, LAYERS
+    from gunet_amd.data import data_utils
+    from gunet_amd.models.graph_unet import GraphUNet
+    for name in ('GeoQuadrantGCN', 'GraphDownsamplingBlock', 'GraphUpsamplingBlock', 'GraphUpsampling2x2',
+                 'graph_pooling_2x2', 'remove_duplicate_edges'):
+        assert hasattr(hybrid_gnn, name)
+    assert hasattr(graph_ops, 'get_sender_receiver') and hasattr(data_utils, 'sample_quadrant_subgraphs')
+    assert data_utils.QUADRANT_IDS[:4] == [[0, 1, 2], [2, 3, 4], [4, 5, 6], [6, 7, 0]]
+    assert get('GEO_QUADRANT_GCN') is hybrid_gnn.GeoQuadrantGCN and 'geo_quadrant_gcn' in LAYERS
+    model = GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                      use_bias=True, use_global=True)
+    prefixes = [p for p, _ in model._gn_layers()]
+    assert len(prefixes) == 14 and prefixes[0] == 'downsampling_layers/0/gcns/0'
+    assert prefixes[-1] == 'upsampling_layers/2/gcns/1'
+    assert not model.upsampling_layers[-1].gcns[-1].has_glob_transform      # last layer: identity global
+    assert all(l.has_glob_transform for _, l in model._gn_layers()[:-1])

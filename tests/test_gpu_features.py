@@ -1,0 +1,234 @@
+"""Feature parity of the HIP kernels with the oracle, through the C ABI.
+
+Tolerance (fp32 path): normwise relative error max|got - want| / max|want| <= 1e-5 for every
+feature tensor; index tensors and max-pooled values must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import gunet_amd
+    return gunet_amd
+
+
+def _layer_weights(oracle, prefix, c_in, f_e, g, seed=1, with_gt=True):
+    return oracle.make_weights(oracle.gn_layer_shapes(prefix, c_in, f_e, g, 128, with_gt), seed)
+
+
+def _run_layer(amd, oracle, x, graph, W, prefix, with_gt=True, batch=None, activation='relu', use_bias=True):
+    layer = amd.hybrid_gnn.GeoQuadrantGCN(128, activation=activation, use_bias=use_bias, use_global=True,
+                                          learn_global_scale=with_gt)
+    layer.load_weights(W, prefix, 'cuda')
+    g = graph_to_dev(graph)
+    xt = to_dev(x)
+    if batch:
+        xt = xt.unsqueeze(0).repeat(batch, 1, 1)
+        g['edges'] = [e.unsqueeze(0).repeat(batch, 1, 1) for e in g['edges']]
+        g['global'] = g['global'].repeat(batch, 1)
+    y, g = layer(xt, g)
+    torch.cuda.synchronize()
+    return y, g
+
+
+def test_dense_forward(amd):
+    rng = np.random.Generator(np.random.PCG64(2))
+    for rows, k, n, bias, act in [(1000, 104, 128, True, None), (333, 128, 96, False, None),
+                                  (257, 64, 256, True, 'relu'), (50, 10, 7, True, 'relu'), (0, 8, 32, True, None)]:
+        x = rng.standard_normal((rows, k)).astype(np.float32)
+        w = rng.standard_normal((k, n)).astype(np.float32) * 0.1
+        b = rng.standard_normal(n).astype(np.float32)
+        layer = amd.hybrid_gnn.Dense(n, activation=act, use_bias=bias)
+        layer.load_weights({'d/kernel': w, 'd/bias': b}, 'd', 'cuda')
+        got = layer(to_dev(x)).cpu().numpy()
+        want = x.astype(np.float64) @ w.astype(np.float64) + (b if bias else 0)
+        if act == 'relu':
+            want = np.maximum(want, 0)
+        assert got.shape == (rows, n)
+        if rows:
+            assert rel_err(got, want) <= TOL, (rows, k, n)
+
+
+def test_get_sender_receiver(amd, oracle):
+    rng = np.random.Generator(np.random.PCG64(3))
+    for width in (32, 7):
+        x = rng.standard_normal((200, width)).astype(np.float32)
+        e = rng.integers(0, 200, (999, 2)).astype(np.int32)
+        s, r = amd.graph_ops.get_sender_receiver(to_dev(x), to_dev(e))
+        ws, wr = oracle.get_sender_receiver(x, e)
+        assert np.array_equal(s.cpu().numpy(), ws) and np.array_equal(r.cpu().numpy(), wr)
+
+
+@pytest.mark.parametrize('shape', [(128, 16, 113), (128, 32, 128), (256, 16, 128), (128, 2, 256), (104, 5, 20)])
+def test_gn_layer_small(amd, oracle, shape):
+    c_in, f_e, g = shape
+    node_loc, ei, d, _ = oracle.synth_road_graph(23, 31, 0.55, 2)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = node_loc.shape[0]
+    x = rng.random((n, c_in)).astype(np.float32)
+    graph = {'edge_index': list(quads), 'node_loc': node_loc,
+             'edges': [rng.random((q.shape[0], f_e)).astype(np.float32) for q in quads],
+             'global': rng.random((1, g)).astype(np.float32)}
+    W = _layer_weights(oracle, 'L', c_in, f_e, g)
+    keep = {}
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L', keep=keep)
+    got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L')
+    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    for q in range(4):
+        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+
+
+def test_gn_layer_variants(amd, oracle):
+    """identity global transform (last layer), linear activation, no bias, batched call."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(17, 19, 0.6, 6)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    rng = np.random.Generator(np.random.PCG64(10))
+    n = node_loc.shape[0]
+    x = (rng.random((n, 128)) - 0.3).astype(np.float32)
+    graph = {'edge_index': list(quads), 'node_loc': node_loc,
+             'edges': [(rng.random((q.shape[0], 32)) - 0.5).astype(np.float32) for q in quads],
+             'global': rng.random((1, 128)).astype(np.float32)}
+    W = _layer_weights(oracle, 'L', 128, 32, 128, with_gt=False)
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
+    got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L', with_gt=False)
+    assert want_g['global'].shape == (1, 288) and tuple(got_g['global'].shape) == (1, 288)
+    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+
+    W = _layer_weights(oracle, 'L', 128, 32, 128)
+    for act, bias in ((None, True), ('relu', False)):
+        want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L', activation=act, use_bias=bias)
+        got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L', activation=act, use_bias=bias)
+        assert rel_err(got_x.cpu().numpy(), want_x) <= TOL, (act, bias)
+        assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL, (act, bias)
+        for q in range(4):
+            assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+
+    got_b, got_gb = _run_layer(amd, oracle, x, graph, W, 'L', batch=3, use_bias=False)
+    for b in range(3):                      # every sample of a batch equals the single-sample call, bit for bit
+        assert torch.equal(got_b[b], got_x)
+        assert torch.equal(got_gb['global'][b], got_g['global'][0])
+
+
+def test_gn_layer_errors(amd, oracle):
+    with pytest.raises(AttributeError):
+        amd.hybrid_gnn.GeoQuadrantGCN(128, combination='additive')
+    with pytest.raises(NotImplementedError):
+        amd.layers.get('no_such_layer')
+    layer = amd.hybrid_gnn.GeoQuadrantGCN(128, activation='relu', use_bias=True, use_global=True)
+    x = torch.zeros((4, 128), device='cuda')
+    e = [torch.zeros((0, 2), dtype=torch.int32, device='cuda')] * 4
+    with pytest.raises(KeyError):
+        layer(x, {'edge_index': e, 'edges': [torch.zeros((0, 32), device='cuda')] * 4})
+    up = amd.hybrid_gnn.GraphUpsampling2x2(128, method='nearest')
+    with pytest.raises(NotImplementedError):
+        up(x, {}, {})
+
+
+def test_gn_layer_config1_road_graph(amd, oracle):
+    """Single HybridGNN block, 4 quadrant subgraphs, 495x436 road graph, batch 1, D0 shapes."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(495, 436, 0.45, 0)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    rng = np.random.Generator(np.random.PCG64(1))
+    n = node_loc.shape[0]
+    x = rng.random((n, 128)).astype(np.float32)
+    graph = {'edge_index': list(quads), 'node_loc': node_loc,
+             'edges': [rng.random((q.shape[0], 16)).astype(np.float32) for q in quads],
+             'global': rng.random((1, 113)).astype(np.float32)}
+    W = _layer_weights(oracle, 'L', 128, 16, 113)
+    keep = {}
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L', keep=keep)
+    got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L')
+    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    for q in range(4):
+        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    # run twice: all reductions are ordered, so the result is bitwise reproducible
+    again_x, again_g = _run_layer(amd, oracle, x, graph, W, 'L')
+    assert torch.equal(again_x, got_x) and torch.equal(again_g['global'], got_g['global'])
+
+
+def test_pooling_features_bit_exact(amd, oracle):
+    """Pool / upsample chain (levels 0->1->2->3): max-pooled features are exact."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(61, 47, 0.5, 8)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    rng = np.random.Generator(np.random.PCG64(12))
+    batch = 4
+    x = rng.standard_normal((batch, node_loc.shape[0], 128)).astype(np.float32)
+    feats = [rng.standard_normal((batch, q.shape[0], 32)).astype(np.float32) for q in quads]
+    g = {'edge_index': [to_dev(q, torch.int32) for q in quads], 'node_loc': to_dev(node_loc, torch.int64),
+         'edges': [to_dev(f) for f in feats]}
+    xt = to_dev(x)
+    want = []
+    for b in range(batch):
+        gb = {'edge_index': list(quads), 'node_loc': node_loc, 'edges': [f[b] for f in feats]}
+        xb = x[b]
+        per = []
+        for _ in range(3):
+            xb, gb = oracle.graph_pooling_2x2(xb, gb)
+            per.append((xb, [e for e in gb['edges']]))
+        want.append(per)
+    for lvl in range(3):
+        xt, g = amd.hybrid_gnn.graph_pooling_2x2(xt, g)
+        for b in range(batch):
+            assert np.array_equal(xt[b].cpu().numpy(), want[b][lvl][0])
+            for q in range(4):
+                assert np.array_equal(g['edges'][q][b].cpu().numpy(), want[b][lvl][1][q])
+
+
+def _unet(amd, oracle, W):
+    model = amd.GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                          use_bias=True, use_global=True, output_activation=None)
+    return model.load_weights(W, 'cuda')
+
+
+@pytest.mark.parametrize('size', [(12, 16, 0.6), (40, 52, 0.45)])
+def test_graph_unet_small(amd, oracle, size):
+    x, graph, _ = make_case(oracle, *size)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    keep = {}
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W, keep=keep)
+    model = _unet(amd, oracle, W)
+    got_y, got_g = model(to_dev(x), graph_to_dev(graph))
+    assert tuple(got_y.shape) == want_y.shape
+    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    for q in range(4):
+        assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), want_g['edge_index'][q])
+        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+    assert np.array_equal(got_g['node_loc'].cpu().numpy(), want_g['node_loc'])
+
+
+def test_graph_unet_config2_road_graph(amd, oracle):
+    """Full GraphUNet at checkpoint shapes on the 495x436 road graph; batch of 2 samples checked
+    against two single-sample oracle runs."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(495, 436, 0.45, 0)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    enc = oracle.synth_street_encoding(node_loc.shape[0], 5)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    xs, graphs = [], []
+    for b in range(2):
+        sn, te, wd = oracle.synth_sample(node_loc, quads, 100 + b, time_idx=12 * b, weekday=b)
+        x, graph = oracle.assemble_inputs(sn, enc, quads, node_loc, te, wd)
+        xs.append(x)
+        graphs.append(graph)
+    model = _unet(amd, oracle, W)
+    g = graph_to_dev(graphs[0])
+    g['edges'] = [torch.stack([to_dev(gr['edges'][q]) for gr in graphs]) for q in range(4)]
+    g['global'] = torch.cat([to_dev(gr['global']) for gr in graphs], dim=0)
+    got_y, got_g = model(torch.stack([to_dev(x) for x in xs]), g)
+    got_y = torch.clamp_min(got_y, 0).cpu().numpy()
+    for b in range(2):
+        want_y, want_g = oracle.predict(xs[b], copy_graph(graphs[b]), W)
+        assert rel_err(got_y[b], want_y) <= TOL, b
+        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
