@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Benchmark of the Graph U-Net forward hot path on MI355X.
+
+Workload (N = 1): full GraphUNet forward at the shipped checkpoint's shapes (12x8-channel input,
+12x8-channel output, width 128, depth 3, 14 GeoQuadrantGCN layers) on one synthetic 495x436 road
+graph (mask density 0.45, seed 0), a batch of 8 independent (city, time-window) samples, float32.
+One "step" = one forward of the batch with inputs resident in HBM and the per-city index plan
+cached (the plan build is timed separately and reported in `config`).
+
+With --gpus N > 1 every rank runs its own batch (weak scaling, no collective inside the forward);
+per step the predictions are gathered on rank 0 and a small metrics vector is all-reduced over
+RCCL, overlapped with the next step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='samples per GPU per step')
+    ap.add_argument('--height', type=int, default=495)
+    ap.add_argument('--width', type=int, default=436)
+    ap.add_argument('--density', type=float, default=0.45)
+    ap.add_argument('--dense', action='store_true', help='all pixels are nodes (MFMA stress graph)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-runs', type=int, default=3)
+    ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel event pass')
+    return ap.parse_args()
+
+
+def cpu_baseline(args, graph_np, weights, inputs_np):
+    """Time the CPU restatement (oracle/, numpy) of the same forward on one sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    import gunet_oracle as O
+    node_loc, quads = graph_np
+    x, edges, glob = inputs_np
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get('OMP_NUM_THREADS', '1'))
+    times = []
+    for i in range(args.cpu_runs + 1):
+        graph = {'edge_index': list(quads), 'edges': list(edges), 'node_loc': node_loc, 'global': glob}
+        t0 = time.perf_counter()
+        y, _ = O.predict(x, graph, weights)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    med = float(np.median(times))
+    return {'value': 1.0 / med, 'unit': 'samples/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{args.cpu_runs} timed single-sample forwards (median {med:.3f} s) after 1 warm-up, '
+                      'same graph, weights and first sample as the GPU run; numpy oracle, unfused reference op order'}, y
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    import gunet_amd
+    from gunet_amd import synthetic, workload, sharding, _lib
+
+    # ---- workload -----------------------------------------------------------------------
+    if args.dense:
+        node_loc, edge_index, direction = synthetic.dense_graph(args.height, args.width)
+    else:
+        node_loc, edge_index, direction = synthetic.road_graph(args.height, args.width, args.density, 0)
+    n_nodes = node_loc.shape[0]
+    weights = synthetic.random_weights(synthetic.graph_unet_shapes(), 1)
+    model = gunet_amd.GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                                use_bias=True, use_global=True, output_activation=None)
+    model.load_weights(weights, dev)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    quads = gunet_amd.data_utils.sample_quadrant_subgraphs(torch.as_tensor(edge_index).to(dev),
+                                                           torch.as_tensor(direction).to(dev))
+    torch.cuda.synchronize()
+    partition_ms = (time.perf_counter() - t0) * 1e3
+    quads_np = [q.cpu().numpy() for q in quads]
+
+    enc = synthetic.street_encoding(n_nodes, 5)
+    B = args.batch
+    xs, globs, first = [], [], None
+    for b in range(B):
+        sid = rank * B + b
+        sn, te, wd = synthetic.sample_inputs(n_nodes, 1000 + sid, time_idx=12 * sid, weekday=sid)
+        x, edges_np, glob = synthetic.assemble_model_inputs(sn, enc, quads_np, te, wd)
+        if first is None:
+            first = (x, edges_np, glob)
+        xs.append(torch.as_tensor(x))
+        globs.append(torch.as_tensor(glob))
+    x_dev = torch.stack(xs).to(dev)                                   # [B, N, 104]
+    glob_dev = torch.cat(globs, dim=0).to(dev)                        # [B, 113]
+    edges_dev = [torch.as_tensor(e).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous() for e in first[1]]
+    node_loc_dev = torch.as_tensor(node_loc).to(dev)
+    del xs, globs
+
+    def forward():
+        graph = {'edge_index': list(quads), 'edges': list(edges_dev), 'node_loc': node_loc_dev,
+                 'global': glob_dev}
+        return model.predict(x_dev, graph)
+
+    # first call builds (and caches) every plan of this city
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y = forward()
+    torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - t0) * 1e3
+
+    out_bufs = [torch.empty_like(y) for _ in range(2)]
+    gathered = [None, None]
+    if world > 1 and rank == 0:
+        gathered = [torch.empty((world,) + tuple(y.shape), dtype=y.dtype, device=dev) for _ in range(2)]
+    pending = [None, None]
+    metrics = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def step(i):
+        y = forward()
+        if world > 1:
+            slot = i & 1
+            if pending[slot] is not None:
+                for w in pending[slot]:
+                    w.wait()
+            out_bufs[slot].copy_(y)
+            m = torch.stack((out_bufs[slot].sum(dtype=torch.float64),
+                             torch.tensor(float(y.shape[0]), dtype=torch.float64, device=dev)))
+            works = [dist.all_reduce(m, async_op=True)]
+            if rank == 0:
+                works.append(dist.gather(out_bufs[slot], gather_list=list(gathered[slot].unbind(0)), dst=0,
+                                         async_op=True))
+            else:
+                works.append(dist.gather(out_bufs[slot], gather_list=None, dst=0, async_op=True))
+            pending[slot] = works
+            metrics.copy_(m)
+        return y
+
+    def drain():
+        for slot in range(2):
+            if pending[slot] is not None:
+                for w in pending[slot]:
+                    w.wait()
+                pending[slot] = None
+
+    for i in range(args.warmup):
+        y = step(i)
+    drain()
+
+    # ---- timed region -------------------------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        y = step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    samples_per_s = world * B * args.steps / elapsed
+
+    # ---- per-kernel-class pass: HIP events around every launch, same steps again ------------
+    prof = None
+    if not args.no_profile:
+        _lib.profile_enable(True)
+        for i in range(args.steps):
+            forward()
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- algorithmic work and roofline ----------------------------------------------------
+    loc, edges = node_loc_dev, list(quads)
+    n_levels, e_levels = [n_nodes], [sum(int(q.shape[0]) for q in quads)]
+    for _ in range(3):
+        pp = gunet_amd.plan.get_pool_plan(loc, edges)
+        loc, edges = pp.pooled_loc, pp.edge_index
+        n_levels.append(pp.n_pooled)
+        e_levels.append(sum(pp.n_pooled_edges))
+    work = workload.work_per_sample(workload.layer_table(n_levels, e_levels))
+    result = {
+        'metric': 'GraphUNet fwd samples/sec (495x436 grid)', 'value': samples_per_s, 'unit': 'samples/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {
+            'workload': ('full GraphUNet fwd, checkpoint shapes (12x8-ch in, 6x... 12x8-ch out, width 128, depth 3), '
+                         f'one {args.height}x{args.width} ' + ('dense grid' if args.dense else f'road graph (density {args.density}, seed 0)')
+                         + f', batch {B} per GPU'),
+            'nodes_per_level': n_levels, 'quadrant_edges_per_level': e_levels, 'batch_per_gpu': B,
+            'parallelism': f'replicas x{world}, batch-sharded' + (', RCCL gather of outputs to rank 0 + metrics all-reduce per step' if world > 1 else ''),
+            'plan': 'cached', 'plan_build_ms_first_call': first_call_ms, 'quadrant_partition_ms': partition_ms,
+            'gflop_per_sample': work['total_flops'] / 1e9, 'compulsory_GB_per_sample': work['compulsory_bytes'] / 1e9,
+        },
+    }
+    result['config']['workload'] = result['config']['workload'].replace('6x... ', '')
+    if prof is not None:
+        steps = args.steps
+        per_class = {k: {'ms_per_step': v[0] / steps, 'launches_per_step': v[1] / steps} for k, v in prof.items() if v[1]}
+        result['kernels'] = per_class
+        gemm_ms, gemm_n = prof['gemm_f32']
+        edge_ms, edge_n = prof['edge_mlp']
+        agg_ms, agg_n = prof['aggregate']
+        # dominant kernel = the class with the most device time
+        dom = max(('gemm_f32', 'edge_mlp', 'aggregate'), key=lambda k: prof[k][0])
+        if dom == 'aggregate':
+            per_launch = B * work['aggregate_bytes'] / work['aggregate_launches']
+            achieved = per_launch / (agg_ms / agg_n * 1e-3) / 1e9
+            result['roofline'] = {'kernel': 'k_aggregate', 'bound': 'hbm', 'achieved': achieved,
+                                  'peak': workload.PEAK_HBM_GBPS, 'unit': 'GB/s',
+                                  'frac': achieved / workload.PEAK_HBM_GBPS, 'traffic': None}
+        else:
+            flops, ms, n = ((work['gemm_flops'], gemm_ms, gemm_n) if dom == 'gemm_f32'
+                            else (work['edge_flops'], edge_ms, edge_n))
+            launches_per_step = n / steps
+            per_launch = B * flops / launches_per_step
+            achieved = per_launch / (ms / n * 1e-3) / 1e12
+            result['roofline'] = {'kernel': 'k_gemm_f32' if dom == 'gemm_f32' else 'k_edge_mlp', 'bound': 'mfma',
+                                  'achieved': achieved, 'peak': workload.PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': achieved / workload.PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                                  'avg_launch_ms': ms / n, 'algorithmic_gflop_per_launch': per_launch / 1e9}
+        if agg_n:
+            agg_gbps = B * work['aggregate_bytes'] * steps / (agg_ms * 1e-3) / 1e9
+            gs_gbps = B * (work['aggregate_bytes'] + work['gather_bytes']) * steps / ((agg_ms + edge_ms) * 1e-3) / 1e9
+            result['gather_scatter'] = {
+                'aggregate_GBps': agg_gbps, 'aggregate_frac_of_hbm_peak': agg_gbps / workload.PEAK_HBM_GBPS,
+                'aggregate_avg_launch_ms': agg_ms / agg_n,
+                'gather_plus_aggregate_logical_GBps': gs_gbps,
+                'note': 'logical bytes: gathers 4(2Eu+2E) are fused into the edge-MLP kernel, segment-sum 4(Eu+E+NU) is k_aggregate'}
+        mfma_ms = gemm_ms + edge_ms
+        if mfma_ms > 0:
+            tf = B * work['total_flops'] * steps / (mfma_ms * 1e-3) / 1e12
+            result['mfma_utilisation'] = {'tflops_over_gemm_and_edge_kernels': tf, 'frac_of_f32_peak': tf / workload.PEAK_F32_MFMA_TFLOPS}
+    if world == 1 and not args.no_cpu_baseline:
+        base, y_cpu = cpu_baseline(args, (node_loc, quads_np), weights, first)
+        result['cpu_baseline'] = base
+        got = y[0].cpu().numpy()
+        result['parity_rel_err_vs_cpu'] = float(np.abs(got - y_cpu).max() / np.abs(y_cpu).max())
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -46,6 +46,9 @@ class GnWeightsStruct(C.Structure):
 
 VoidP4 = C.c_void_p * 4
 I64x4 = C.c_int64 * 4
+PROF_CLASSES = 8
+F64xP = C.c_double * PROF_CLASSES
+I64xP = C.c_int64 * PROF_CLASSES
 
 # name -> (restype, argtypes); every symbol declared in include/gunet_hip.h
 SIGNATURES = {
@@ -78,6 +81,9 @@ SIGNATURES = {
                                              C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_void_p,
                                              C.POINTER(VoidP4), C.c_void_p, C.c_void_p,
                                              C.c_size_t, C.c_void_p]),
+    'gunet_profile_enable': (C.c_int, [C.c_int]),
+    'gunet_profile_collect': (C.c_int, [C.POINTER(F64xP), C.POINTER(I64xP)]),
+    'gunet_profile_class_name': (C.c_char_p, [C.c_int]),
 }
 
 
@@ -125,3 +131,14 @@ def ptr4(tensors):
 def current_stream(device):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def profile_enable(on):
+    call('gunet_profile_enable', 1 if on else 0)
+
+
+def profile_collect():
+    """{class name: (milliseconds, launches)} since the previous collect."""
+    ms, n = F64xP(), I64xP()
+    call('gunet_profile_collect', C.byref(ms), C.byref(n))
+    return {lib.gunet_profile_class_name(c).decode(): (float(ms[c]), int(n[c])) for c in range(PROF_CLASSES)}

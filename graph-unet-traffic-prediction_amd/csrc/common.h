@@ -67,6 +67,35 @@ class DevBuf {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Kernel classes of the optional event profiler (gunet_profile_*).
+enum ProfClass {
+  kProfGemm = 0,
+  kProfEdgeMlp,
+  kProfAggregate,
+  kProfPrologue,
+  kProfGlobalUpdate,
+  kProfSegment,
+  kProfGather,
+  kProfDenseNaive,
+  kProfCount
+};
+static_assert(kProfCount == GUNET_PROF_CLASSES, "profiler class table out of step with the header");
+
+// Brackets the launches issued during its lifetime with two events when profiling is enabled.
+class ProfScope {
+ public:
+  ProfScope(int cls, hipStream_t stream);
+  ~ProfScope();
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+
+ private:
+  int cls_;
+  hipStream_t stream_;
+  void* start_ = nullptr;
+  void* stop_ = nullptr;
+};
+
 inline hipStream_t as_stream(gunet_stream_t s) { return static_cast<hipStream_t>(s); }
 
 // Exclusive prefix sum of `n` int32 values into out[0..n] (n + 1 entries; out[n] = total).

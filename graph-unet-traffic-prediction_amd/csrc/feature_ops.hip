@@ -98,6 +98,7 @@ int launch_segment_reduce(const float* src, int64_t n_src, int32_t width, const 
                    (reinterpret_cast<uintptr_t>(out) % 16 == 0);
   const int64_t work = n_segments * (vec ? width / 4 : width);
   dim3 grid(static_cast<unsigned>(ceil_div(work, kThreads)), static_cast<unsigned>(batch));
+  ProfScope prof(kProfSegment, stream);
   if (vec)
     k_segment_reduce<4, IS_MAX><<<grid, kThreads, 0, stream>>>(src, n_src, width, rowptr, perm,
                                                                n_segments, scale, out);
@@ -286,6 +287,7 @@ __global__ void k_dense_naive(const float* __restrict__ x, int64_t rows, int k,
 int launch_gemm(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
   if (g.n_rows == 0 || batch == 0) return GUNET_OK;
   dim3 grid(static_cast<unsigned>(ceil_div(g.n_rows, kBM)), static_cast<unsigned>(batch));
+  ProfScope prof(kProfGemm, stream);
   switch (nt) {
     case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(g); break;
     case 2: k_gemm_f32<2><<<grid, kThreads, 0, stream>>>(g); break;
@@ -612,6 +614,7 @@ int gunet_get_sender_receiver_f32(const float* x, int64_t n_nodes, int32_t width
                    reinterpret_cast<uintptr_t>(receivers) % 16 == 0;
   const int64_t work = n_edges * (vec ? width / 4 : width);
   const unsigned grid = static_cast<unsigned>(ceil_div(work, kThreads));
+  ProfScope prof(kProfGather, as_stream(stream));
   if (vec)
     k_gather_rows<4><<<grid, kThreads, 0, as_stream(stream)>>>(x, width, edge_index, n_edges,
                                                                senders, receivers);
@@ -654,6 +657,7 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
                      reinterpret_cast<uintptr_t>(kernel) % 16 == 0;
   if (!tiled) {
     const unsigned grid = static_cast<unsigned>(ceil_div(rows * n_out, kThreads));
+    ProfScope prof(kProfDenseNaive, stream);
     k_dense_naive<<<grid, kThreads, 0, stream>>>(x, rows, k, kernel, bias, n_out,
                                                  activation == GUNET_ACT_RELU, out);
     GUNET_LAUNCH_CHECK();
@@ -747,9 +751,12 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
   p.gsn = w->global_scale_nodes;
   p.gse = w->global_scale_edges;
 
-  k_layer_prologue<<<batch, 128, sizeof(float) * (w->g + 4 * kU), stream>>>(p, global_in, relu, ws.nbias,
-                                                                            ws.ebias, ws.gbias);
-  GUNET_LAUNCH_CHECK();
+  {
+    ProfScope prof(kProfPrologue, stream);
+    k_layer_prologue<<<batch, 128, sizeof(float) * (w->g + 4 * kU), stream>>>(p, global_in, relu, ws.nbias,
+                                                                              ws.ebias, ws.gbias);
+    GUNET_LAUNCH_CHECK();
+  }
 
   {  // node embeddings of the four directions in one GEMM (hybrid_gnn.py:91-92)
     GemmArgs g = {};
@@ -794,6 +801,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     for (int q = 0; q < 4; ++q)
       if (graph->n_edges[q] > 0 && edges[q] == nullptr) all_feat = false;
     dim3 grid(static_cast<unsigned>(ws.n_eblk), 4, static_cast<unsigned>(batch));
+    ProfScope prof(kProfEdgeMlp, stream);
     const int chunks = (!any_feat || w->f_e == 0) ? 0 : (w->f_e + 7) / 8;
     if (chunks == 0) {
       k_edge_mlp<0, false><<<grid, kThreads, 0, stream>>>(a);
@@ -825,6 +833,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     a.scale = 1.0f / (3 + 1);
     a.agg = ws.agg;
     dim3 grid(static_cast<unsigned>(ceil_div(n, kThreads / 32)), static_cast<unsigned>(batch));
+    ProfScope prof(kProfAggregate, stream);
     k_aggregate<<<grid, kThreads, 0, stream>>>(a);
     GUNET_LAUNCH_CHECK();
   }
@@ -854,9 +863,12 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_TRY(launch_gemm(g, 4, batch, stream));
   }
 
-  k_global_update<<<batch, 128, sizeof(float) * (w->g + kUnits + kU), stream>>>(
-      p, global_in, ws.npart, n > 0 ? ws.n_nblk : 0, ws.epart, ws.n_eblk, relu, global_out);
-  GUNET_LAUNCH_CHECK();
+  {
+    ProfScope prof(kProfGlobalUpdate, stream);
+    k_global_update<<<batch, 128, sizeof(float) * (w->g + kUnits + kU), stream>>>(
+        p, global_in, ws.npart, n > 0 ? ws.n_nblk : 0, ws.epart, ws.n_eblk, relu, global_out);
+    GUNET_LAUNCH_CHECK();
+  }
   return GUNET_OK;
 }
 

@@ -73,7 +73,9 @@ class Dense:
             out[prefix + '/bias'] = self.bias
         return out
 
-    def __call__(self, x):
+    def __call__(self, x, activation=Ellipsis):
+        """activation overrides the layer's own for this call (used to fuse a following ReLU)."""
+        act = self._act if activation is Ellipsis else _activation_code(activation)
         x = _as_f32(x, 'x')
         self.build(x.shape[-1], x.device)
         if x.shape[-1] != self.kernel.shape[0]:
@@ -81,7 +83,7 @@ class Dense:
         rows = x.numel() // x.shape[-1]
         out = torch.empty(x.shape[:-1] + (self.units,), dtype=torch.float32, device=x.device)
         call('gunet_dense_forward_f32', ptr(x), rows, x.shape[-1], ptr(self.kernel), ptr(self.bias),
-             self.units, self._act, ptr(out), current_stream(x.device))
+             self.units, act, ptr(out), current_stream(x.device))
         return out
 
 

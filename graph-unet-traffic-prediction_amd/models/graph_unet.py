@@ -70,7 +70,14 @@ class GraphUNet:
                 out.update(layer.named_weights(prefix))
         return out
 
-    def call(self, x, graph, training=False):
+    def predict(self, x, graph, training=False):
+        """max(GraphUNet(x, graph), 0): what GraphBaseModel._call returns for the forward
+        (reference models/base_model.py:314,325); the clamp is fused into the output GEMM."""
+        if self.out_model.activation not in (None, 'linear', 'relu'):
+            raise NotImplementedError('predict() needs a linear or relu output activation')
+        return self.call(x, graph, training=training, _out_activation='relu')[0]
+
+    def call(self, x, graph, training=False, _out_activation=Ellipsis):
         skip_graphs = []
         skips = []
         x = self.in_layer(x)
@@ -82,7 +89,7 @@ class GraphUNet:
         x, graph = self.bottleneck_gcn_2(x, graph)
         for di, layer in enumerate(self.upsampling_layers):
             x, graph = layer(x, graph, skips[-(di + 1)], skip_graphs[-(di + 1)])
-        x = self.out_model(x)
+        x = self.out_model(x, activation=_out_activation)
         return x, graph
 
     __call__ = call

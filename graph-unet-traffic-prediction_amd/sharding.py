@@ -1,0 +1,71 @@
+"""Batch sharding of independent (city, time-window) samples over the GPUs of one node.
+
+The reference runs one sample per call in one process (train_utils.py:69-72; its batched-graph
+path does not exist), so a multi-GPU run is a set of replicas: each rank owns a contiguous block
+of the sample list (grouped by city, so a rank builds only the plans it needs), weights are
+replicated and no data moves between ranks inside a forward.  torch.distributed (RCCL on GPUs,
+gloo on CPUs) is used for two things only: gathering the predictions on one rank and summing the
+metric numerators.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous block [lo, hi) of rank `rank`; the first n_items % world_size ranks get one extra."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_by_city(sample_cities, world_size, rank):
+    """Indices of the samples rank `rank` runs.  Samples are ordered by city first (stable), then
+    cut into contiguous blocks, so one rank touches as few cities as possible."""
+    order = sorted(range(len(sample_cities)), key=lambda i: sample_cities[i])
+    lo, hi = shard_bounds(len(order), world_size, rank)
+    return order[lo:hi]
+
+
+def gather_rows(local, dst=0, group=None):
+    """Gather variable-length [n_i, ...] tensors on rank dst (concatenated in rank order; None on
+    the other ranks).  Row counts may differ between ranks (cities differ in node count)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = torch.zeros(world, dtype=torch.int64, device=local.device)
+    counts[rank] = local.shape[0]
+    dist.all_reduce(counts, group=group)
+    counts = counts.tolist()
+    local = local.contiguous()
+    if rank == dst:
+        parts = [local if r == rank else
+                 torch.empty((counts[r],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+                 for r in range(world)]
+        reqs = [dist.irecv(parts[r], src=r, group=group) for r in range(world) if r != rank and counts[r] > 0]
+        for req in reqs:
+            req.wait()
+        return torch.cat(parts, dim=0)
+    if counts[rank] > 0:
+        dist.isend(local, dst=dst, group=group).wait()
+    return None
+
+
+def gather_equal(local, dst=0, group=None, out=None):
+    """Gather same-shaped tensors on rank dst as one [world, ...] tensor (None elsewhere)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local.unsqueeze(0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local.contiguous(), gather_list=list(out.unbind(0)), dst=dst, group=group)
+        return out
+    dist.gather(local.contiguous(), gather_list=None, dst=dst, group=group)
+    return None
+
+
+def sum_metrics(values, group=None):
+    """All-reduce (sum) a small tensor of metric numerators / counts."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, group=group)
+    return values

@@ -169,6 +169,20 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
                                float* const edges_out[4], float* global_out, void* workspace,
                                size_t workspace_bytes, gunet_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * 3. Measurement -- no counterpart in the reference
+ * ------------------------------------------------------------------------ */
+
+/* Per-kernel-class device timing.  While enabled, every kernel launch of the feature functions
+ * is bracketed by two hipEvents on its stream; gunet_profile_collect() waits for them and
+ * returns the summed milliseconds and the launch count per class since the previous collect.
+ * Classes: 0 gemm_f32, 1 edge_mlp, 2 aggregate, 3 layer_prologue, 4 global_update,
+ * 5 segment_reduce, 6 gather_rows, 7 dense_naive. */
+#define GUNET_PROF_CLASSES 8
+int gunet_profile_enable(int on);
+int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_host[GUNET_PROF_CLASSES]);
+const char* gunet_profile_class_name(int cls);
+
 #ifdef __cplusplus
 }
 #endif

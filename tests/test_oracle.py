@@ -207,3 +207,27 @@ def test_fp32_oracle_close_to_float64_restatement(oracle):
     y64, _ = oracle.graph_unet_forward(z['x'].astype(np.float64), graph, W64)
     assert y64.dtype == np.float64
     assert rel_err(z['y'], y64) < 2e-6
+
+
+def test_synthetic_generators_match_oracle(oracle):
+    """The package's workload generators (used by bench.py) produce exactly the oracle's data."""
+    from gunet_amd import synthetic
+    for h, w, dens, seed in [(9, 14, 0.6, 3), (60, 45, 0.45, 0), (30, 30, 1.1, 1)]:
+        node_loc, ei, d, _ = oracle.synth_road_graph(h, w, dens, seed)
+        nl2, ei2, d2 = synthetic.road_graph(h, w, dens, seed)
+        assert np.array_equal(node_loc, nl2) and np.array_equal(ei, ei2) and np.array_equal(d, d2)
+        assert ei2.dtype == np.int32 and nl2.dtype == np.int64 and d2.dtype == np.int64
+    assert synthetic.graph_unet_shapes() == oracle.graph_unet_shapes()
+    W1, W2 = oracle.make_weights(oracle.graph_unet_shapes(), 1), synthetic.random_weights(synthetic.graph_unet_shapes(), 1)
+    assert all(np.array_equal(W1[k], W2[k]) for k in W1)
+    node_loc, ei, d, _ = oracle.synth_road_graph(20, 20, 0.5, 2)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    enc = oracle.synth_street_encoding(node_loc.shape[0], 5)
+    assert np.array_equal(enc, synthetic.street_encoding(node_loc.shape[0], 5))
+    sn, te, wd = oracle.synth_sample(node_loc, quads, 7, time_idx=24, weekday=3)
+    sn2, te2, wd2 = synthetic.sample_inputs(node_loc.shape[0], 7, time_idx=24, weekday=3)
+    assert np.array_equal(sn, sn2) and np.array_equal(te, te2) and np.array_equal(wd, wd2)
+    x, graph = oracle.assemble_inputs(sn, enc, quads, node_loc, te, wd)
+    x2, edges2, glob2 = synthetic.assemble_model_inputs(sn2, enc, quads, te2, wd2)
+    assert np.array_equal(x, x2) and np.array_equal(graph['global'], glob2)
+    assert all(np.array_equal(a, b) for a, b in zip(graph['edges'], edges2))
