@@ -320,46 +320,69 @@ struct LayerPtrs {
   float gsn, gse;
 };
 
+constexpr int kSmallThreads = 1024;   // the two per-sample kernels: 8 k-groups x 128 columns
+constexpr int kGroups = kSmallThreads / kUnits;
+
+// Sum of `n` per-group partials for column `col`, in group order.
+__device__ inline float combine_groups(const float* part, int col) {
+  float s = part[col];
+#pragma unroll
+  for (int g = 1; g < kGroups; ++g) s += part[g * kUnits + col];
+  return s;
+}
+
 // Per sample: the chained global transforms (hybrid_gnn.py:98-99), folded into the bias each
 // direction's edge MLP sees; the node MLP's global columns folded into its bias (:122-125);
-// and the four node-embedding biases laid side by side.
-__global__ __launch_bounds__(128) void k_layer_prologue(LayerPtrs p, const float* __restrict__ global_in,
-                                                        int relu, float* __restrict__ nbias,
-                                                        float* __restrict__ ebias,
-                                                        float* __restrict__ gbias) {
+// and the four node-embedding biases laid side by side.  Every dot product is split over 8
+// thread groups by k (k = group, group + 8, ...) and the 8 partials are added in group order.
+__global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
+                                                                  const float* __restrict__ global_in,
+                                                                  int relu, float* __restrict__ nbias,
+                                                                  float* __restrict__ ebias,
+                                                                  float* __restrict__ gbias) {
   extern __shared__ float sh[];
-  float* gl = sh;            // [g]
-  float* gq = sh + p.g;      // [4][32]
+  float* gl = sh;                      // [g]
+  float* gq = gl + p.g;                // [4][32]
+  float* part = gq + 4 * kU;           // [8][128]
   const int tid = threadIdx.x;
+  const int grp = tid >> 7, col = tid & 127;
   const int64_t b = blockIdx.x;
   for (int k = tid; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
   __syncthreads();
   for (int q = 0; q < 4; ++q) {
-    if (tid < kU) {
-      const float* src = q == 0 ? gl : gq + (q - 1) * kU;
-      const int kk = q == 0 ? p.g : kU;
+    const float* src = q == 0 ? gl : gq + (q - 1) * kU;
+    const int kk = q == 0 ? p.g : kU;
+    if (col < kU) {
       float s = 0.0f;
-      for (int k = 0; k < kk; ++k) s = fmaf(src[k], p.glob_w[q][k * kU + tid], s);
+      for (int k = grp; k < kk; k += kGroups) s = fmaf(src[k], p.glob_w[q][k * kU + col], s);
+      part[grp * kUnits + col] = s;
+    }
+    __syncthreads();
+    if (tid < kU) {
+      float s = combine_groups(part, tid);
       if (p.glob_b[q]) s += p.glob_b[q][tid];
       gq[q * kU + tid] = activate(s, relu);
     }
     __syncthreads();
   }
   {
-    const int q = tid >> 5, j = tid & 31;
-    const float* w = p.edge_w[q] + static_cast<int64_t>(p.f_e + 2 * kU) * kU;
-    float s = 0.0f;
-    for (int k = 0; k < kU; ++k) s = fmaf(gq[q * kU + k], w[k * kU + j], s);
-    if (p.edge_b[q]) s += p.edge_b[q][j];
-    ebias[b * kUnits + tid] = s;
-    if (b == 0) nbias[tid] = p.node_emb_b[q] ? p.node_emb_b[q][j] : 0.0f;
-  }
-  {
     const float* w = p.node_w + static_cast<int64_t>(p.c_in + kUnits) * kUnits;
     float s = 0.0f;
-    for (int k = 0; k < p.g; ++k) s = fmaf(gl[k], w[static_cast<int64_t>(k) * kUnits + tid], s);
+    for (int k = grp; k < p.g; k += kGroups) s = fmaf(gl[k], w[static_cast<int64_t>(k) * kUnits + col], s);
+    part[grp * kUnits + col] = s;
+  }
+  __syncthreads();
+  if (tid < kUnits) {
+    float s = combine_groups(part, tid);
     if (p.node_b) s += p.node_b[tid];
     gbias[b * kUnits + tid] = s;
+    const int q = tid >> 5, j = tid & 31;
+    const float* w = p.edge_w[q] + static_cast<int64_t>(p.f_e + 2 * kU) * kU;
+    float e = 0.0f;
+    for (int k = 0; k < kU; ++k) e = fmaf(gq[q * kU + k], w[k * kU + j], e);
+    if (p.edge_b[q]) e += p.edge_b[q][j];
+    ebias[b * kUnits + tid] = e;
+    if (b == 0) nbias[tid] = p.node_emb_b[q] ? p.node_emb_b[q][j] : 0.0f;
   }
 }
 
@@ -518,29 +541,49 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
   *reinterpret_cast<float4*>(a.agg + (b * a.n_nodes + v) * kUnits + kU * q + 4 * c4) = acc;
 }
 
-// Per sample: finish the node / edge column sums (fixed order, fp64 accumulation over the
-// per-block partials), scale them and apply the global transform (hybrid_gnn.py:130-135).
-__global__ __launch_bounds__(128) void k_global_update(LayerPtrs p, const float* __restrict__ global_in,
-                                                       const float* __restrict__ npart, int n_nblk,
-                                                       const float* __restrict__ epart, int n_eblk,
-                                                       int relu, float* __restrict__ global_out) {
-  extern __shared__ float gin[];   // [g + 128 + 32]
+// Per sample: finish the node / edge column sums (fp64 accumulation over the per-block
+// partials, block i handled by thread group i mod 8, groups combined in order), scale them and
+// apply the global transform (hybrid_gnn.py:130-135).
+__global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
+                                                                 const float* __restrict__ global_in,
+                                                                 const float* __restrict__ npart, int n_nblk,
+                                                                 const float* __restrict__ epart, int n_eblk,
+                                                                 int relu, float* __restrict__ global_out) {
+  extern __shared__ __attribute__((aligned(16))) float gsh[];
+  double* dpart = reinterpret_cast<double*>(gsh);                    // [8][128]
+  float* part = reinterpret_cast<float*>(dpart + kGroups * kUnits);  // [8][128]
+  float* gin = part + kGroups * kUnits;                              // [g + 128 + 32]
   const int tid = threadIdx.x;
+  const int grp = tid >> 7, col = tid & 127;
   const int64_t b = blockIdx.x;
   for (int k = tid; k < p.g; k += blockDim.x) gin[k] = global_in[b * p.g + k];
   {
     double s = 0.0;
-    const float* src = npart + b * n_nblk * static_cast<int64_t>(kUnits) + tid;
-    for (int i = 0; i < n_nblk; ++i) s += static_cast<double>(src[static_cast<int64_t>(i) * kUnits]);
+    const float* src = npart + b * n_nblk * static_cast<int64_t>(kUnits) + col;
+    for (int i = grp; i < n_nblk; i += kGroups) s += static_cast<double>(src[static_cast<int64_t>(i) * kUnits]);
+    dpart[grp * kUnits + col] = s;
+  }
+  __syncthreads();
+  if (tid < kUnits) {
+    double s = dpart[tid];
+    for (int g = 1; g < kGroups; ++g) s += dpart[g * kUnits + tid];
     const float denom = p.gsn * 300.0f * 300.0f;
     gin[p.g + tid] = (static_cast<float>(s) * 1.0f) / denom;
   }
+  __syncthreads();
+  {
+    const int q = col >> 5, c = col & 31;
+    double s = 0.0;
+    const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(kU) + c;
+    for (int i = grp; i < n_eblk; i += kGroups) s += static_cast<double>(src[static_cast<int64_t>(i) * kU]);
+    dpart[grp * kUnits + col] = s;
+  }
+  __syncthreads();
   if (tid < kU) {
     float total = 0.0f;
     for (int q = 0; q < 4; ++q) {
-      double s = 0.0;
-      const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(kU) + tid;
-      for (int i = 0; i < n_eblk; ++i) s += static_cast<double>(src[static_cast<int64_t>(i) * kU]);
+      double s = dpart[q * kU + tid];
+      for (int g = 1; g < kGroups; ++g) s += dpart[g * kUnits + q * kU + tid];
       total += static_cast<float>(s);
     }
     const float denom = p.gse * 300.0f * 300.0f * 8.0f;
@@ -550,9 +593,14 @@ __global__ __launch_bounds__(128) void k_global_update(LayerPtrs p, const float*
   const int kin = p.g + kUnits + kU;
   if (p.globt_w != nullptr) {
     float s = 0.0f;
-    for (int k = 0; k < kin; ++k) s = fmaf(gin[k], p.globt_w[static_cast<int64_t>(k) * kUnits + tid], s);
-    if (p.globt_b) s += p.globt_b[tid];
-    global_out[b * kUnits + tid] = activate(s, relu);
+    for (int k = grp; k < kin; k += kGroups) s = fmaf(gin[k], p.globt_w[static_cast<int64_t>(k) * kUnits + col], s);
+    part[grp * kUnits + col] = s;
+    __syncthreads();
+    if (tid < kUnits) {
+      float t = combine_groups(part, tid);
+      if (p.globt_b) t += p.globt_b[tid];
+      global_out[b * kUnits + tid] = activate(t, relu);
+    }
   } else {
     for (int k = tid; k < kin; k += blockDim.x) global_out[b * kin + k] = gin[k];
   }
@@ -753,7 +801,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
 
   {
     ProfScope prof(kProfPrologue, stream);
-    k_layer_prologue<<<batch, 128, sizeof(float) * (w->g + 4 * kU), stream>>>(p, global_in, relu, ws.nbias,
+    k_layer_prologue<<<batch, kSmallThreads, sizeof(float) * (w->g + 4 * kU + kGroups * kUnits), stream>>>(p, global_in, relu, ws.nbias,
                                                                               ws.ebias, ws.gbias);
     GUNET_LAUNCH_CHECK();
   }
@@ -865,7 +913,8 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
 
   {
     ProfScope prof(kProfGlobalUpdate, stream);
-    k_global_update<<<batch, 128, sizeof(float) * (w->g + kUnits + kU), stream>>>(
+    k_global_update<<<batch, kSmallThreads,
+                      sizeof(double) * kGroups * kUnits + sizeof(float) * (kGroups * kUnits + w->g + kUnits + kU), stream>>>(
         p, global_in, ws.npart, n > 0 ? ws.n_nblk : 0, ws.epart, ws.n_eblk, relu, global_out);
     GUNET_LAUNCH_CHECK();
   }
