@@ -78,9 +78,13 @@ SIGNATURES = {
                                                     C.c_int32]),
     'gunet_gn_layer_forward_f32': (C.c_int, [C.POINTER(QuadGraphStruct),
                                              C.POINTER(GnWeightsStruct), C.c_int32, C.c_void_p,
-                                             C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_void_p,
-                                             C.POINTER(VoidP4), C.c_void_p, C.c_void_p,
-                                             C.c_size_t, C.c_void_p]),
+                                             C.c_void_p, C.c_int32, C.POINTER(VoidP4), C.c_void_p,
+                                             C.c_int32, C.c_void_p, C.POINTER(VoidP4), C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]),
+    'gunet_gn_upsample_forward_f32': (C.c_int, [C.POINTER(QuadGraphStruct), C.c_int32,
+                                                C.POINTER(GnWeightsStruct), C.c_int32, C.c_void_p,
+                                                C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.c_void_p]),
     'gunet_profile_enable': (C.c_int, [C.c_int]),
     'gunet_profile_collect': (C.c_int, [C.POINTER(F64xP), C.POINTER(I64xP)]),
     'gunet_profile_class_name': (C.c_char_p, [C.c_int]),

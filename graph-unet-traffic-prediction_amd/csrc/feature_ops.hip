@@ -111,10 +111,10 @@ int launch_segment_reduce(const float* src, int64_t n_src, int32_t width, const 
 
 // ---------------------------------------------------------------- GEMM on fp32 MFMA
 
-// out[b, r, :] = act( sum_s A_s[b, r, :] @ W_s + bias[b] ),  r < n_rows, for up to three operand
+// out[b, map(r), :] = act( sum_s A_s[b, r, :] @ W_s + bias[b] ),  r < n_rows, for up to three operand
 // segments that are concatenated along K in the reference (x | aggregated messages, or
 // upsampled x | skip x | aggregated messages).  One workgroup = 128 rows x (32*NT) columns,
-// four waves of 32 rows each; K is consumed in tiles of 32 staged through LDS.
+// four waves of 32 rows each; K is consumed in tiles of 32.
 struct GemmSeg {
   const float* a;      // sample 0, row 0
   int lda;             // row stride (floats); sample stride is n_rows * lda
@@ -126,25 +126,36 @@ struct GemmSeg {
 struct GemmArgs {
   GemmSeg seg[3];
   int n_seg;
-  int n_rows;                 // rows per sample
+  int n_rows;                 // A rows per sample
   const float* bias;          // [.., 32*NT] or null
   int bias_stride;            // floats between samples (0 = shared)
-  float* out;                 // sample 0
+  float* out;                 // sample 0; null = compute the column sums only
   int ldo;
   int out_col0;               // first output column of this launch
-  float* colsum;              // [B][gridDim.x][32*NT] per-block column sums of the output, or null
+  int out_rows;               // rows per sample of the output tensor
+  const int32_t* row_map;     // A row r -> output row row_map[r * row_map_stride] - row_map_sub
+  int row_map_stride;         //   (null = identity)
+  int row_map_sub;
+  float* colsum;              // per-tile column sums of the activated output, or null:
+  int colsum_tiles;           //   [B][colsum_tiles][32*NT], this launch fills tiles
+  int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + gridDim.x - 1
   int relu;
 };
 
 constexpr int kBM = 128;
 constexpr int kBK = 32;
-constexpr int kLda = kBK + 4;   // padded LDS row of the A tile (conflict-free ds_read_b128)
 
+// The A operand goes straight from global memory into MFMA registers: lane (li, lh) of wave w
+// owns row 32w+li of the tile and reads floats 8c+4lh..8c+4lh+3 of every 8-float K chunk of that
+// row, so one 128-bit load feeds four v_mfma_f32_32x32x2_f32 (the two half-waves supply the two
+// k of each MFMA; the k order inside a chunk is a fixed permutation, the same for the weights).
+// Only the weight tile goes through LDS (double-buffered, one barrier per K tile); the next A
+// tile is prefetched in registers.  Epilogue: bias, activation, optional row scatter, and the
+// per-tile column sums (fixed order: 16 rows per lane, half-waves, then the four waves).
 template <int NT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
   constexpr int BN = 32 * NT;
-  __shared__ __attribute__((aligned(16))) float As[kBM * kLda];
-  __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BN];
   __shared__ float red[4 * BN];
 
   const int tid = threadIdx.x;
@@ -152,106 +163,109 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
   const int li = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.y;
   const int row0 = blockIdx.x * kBM;
-
-  // staging assignment: A tile = 128 rows x 8 float4, B tile = 32 rows x 8*NT float4
-  const int a_c4 = tid & 7, a_r = tid >> 3;
-  float4 a_reg[4];
-  float4 b_reg[NT];
+  const int my_row = row0 + 32 * wave + li;
+  const bool row_ok = my_row < g.n_rows;
 
   int n_tiles = 0;
   for (int s = 0; s < g.n_seg; ++s) n_tiles += (g.seg[s].k + kBK - 1) / kBK;
 
-  auto load_tile = [&](int t) {
-    int s = 0;
+  float4 b_reg[NT];
+  auto locate = [&](int t, int& s, int& k0) {
+    s = 0;
     while (true) {
       const int nt = (g.seg[s].k + kBK - 1) / kBK;
       if (t < nt) break;
       t -= nt;
       ++s;
     }
+    k0 = t * kBK;
+  };
+  auto load_a = [&](int t, float4 (&a)[4]) {
+    int s, k0;
+    locate(t, s, k0);
     const GemmSeg& sg = g.seg[s];
-    const int k0 = t * kBK;
-    const float* abase = sg.a + (b * g.n_rows + row0) * static_cast<int64_t>(sg.lda);
+    const float* p = sg.a + (b * g.n_rows + my_row) * static_cast<int64_t>(sg.lda) + k0 + 4 * lh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = a_r + 32 * j;
-      const int k = k0 + 4 * a_c4;
-      if (row0 + r < g.n_rows && k < sg.k)
-        a_reg[j] = *reinterpret_cast<const float4*>(abase + static_cast<int64_t>(r) * sg.lda + k);
+    for (int c = 0; c < 4; ++c) {
+      if (row_ok && k0 + 8 * c + 4 * lh < sg.k)
+        a[c] = *reinterpret_cast<const float4*>(p + 8 * c);
       else
-        a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  // thread (kr = tid / 8, c4 = tid % 8) stages row k0+kr, floats 4c4..4c4+3 of every column tile
+  auto load_b = [&](int t) {
+    int s, k0;
+    locate(t, s, k0);
+    const GemmSeg& sg = g.seg[s];
+    const int k = k0 + (tid >> 3);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int idx = tid + kThreads * j;
-      const int kr = idx / (8 * NT), c4 = idx % (8 * NT);
-      const int k = k0 + kr;
       if (k < sg.k)
-        b_reg[j] = *reinterpret_cast<const float4*>(sg.w[c4 >> 3] +
-                                                    static_cast<int64_t>(k) * sg.ldw + 4 * (c4 & 7));
+        b_reg[j] = *reinterpret_cast<const float4*>(sg.w[j] + static_cast<int64_t>(k) * sg.ldw + 4 * (tid & 7));
       else
         b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_tile = [&]() {
+  auto store_b = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<float4*>(&As[(a_r + 32 * j) * kLda + 4 * a_c4]) = a_reg[j];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int idx = tid + kThreads * j;
-      const int kr = idx / (8 * NT), c4 = idx % (8 * NT);
-      *reinterpret_cast<float4*>(&Bs[kr * BN + 4 * c4]) = b_reg[j];
-    }
+    for (int j = 0; j < NT; ++j)
+      *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) * BN + 32 * j + 4 * (tid & 7)]) = b_reg[j];
   };
 
   f32x16 acc[NT];
+  float bias_v[NT];   // loaded up front: a load inside the epilogue would drain its stores
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int n = 0; n < NT; ++n) {
+    bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * n + li] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+  }
 
-  load_tile(0);
-  store_tile();
+  float4 a_cur[4], a_nxt[4];
+  load_a(0, a_cur);
+  load_b(0);
+  store_b(0);
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
-    if (t + 1 < n_tiles) load_tile(t + 1);
-    // each 8-wide K chunk: half-wave h feeds k = 8c+4h .. 8c+4h+3, one MFMA per component
+    const bool more = t + 1 < n_tiles;
+    if (more) {
+      load_b(t + 1);
+      load_a(t + 1, a_nxt);
+    }
+    const float* bs = Bs[t & 1];
 #pragma unroll
     for (int c = 0; c < kBK / 8; ++c) {
-      const float4 av =
-          *reinterpret_cast<const float4*>(&As[(32 * wave + li) * kLda + 8 * c + 4 * lh]);
-      const float a4[4] = {av.x, av.y, av.z, av.w};
+      const float a4[4] = {a_cur[c].x, a_cur[c].y, a_cur[c].z, a_cur[c].w};
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float bv = Bs[(8 * c + 4 * lh + j) * BN + 32 * n + li];
+          const float bv = bs[(8 * c + 4 * lh + j) * BN + 32 * n + li];
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bv, acc[n], 0, 0, 0);
         }
       }
     }
+    if (more) store_b((t + 1) & 1);
     __syncthreads();
-    if (t + 1 < n_tiles) {
-      store_tile();
-      __syncthreads();
-    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
   }
 
-  // epilogue: accumulator register r of lane (li, lh) is row (r&3) + 8*(r>>2) + 4*lh, column li
-  float* obase = g.out + (b * g.n_rows + row0) * static_cast<int64_t>(g.ldo) + g.out_col0;
-  const float* bias = g.bias ? g.bias + b * g.bias_stride : nullptr;
+  // accumulator register r of lane (li, lh) is row (r&3) + 8*(r>>2) + 4*lh of the wave, column li
+  float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + g.out_col0 + li : nullptr;
   float cs[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const float bv = bias ? bias[32 * n + li] : 0.0f;
-    cs[n] = 0.0f;
+  for (int n = 0; n < NT; ++n) cs[n] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float v = activate(acc[n][r] + bv, g.relu);
-      if (row0 + row < g.n_rows) {
-        obase[static_cast<int64_t>(row) * g.ldo + 32 * n + li] = v;
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (row < g.n_rows) {
+      const int64_t orow = g.row_map ? g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub : row;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float v = activate(acc[n][r] + bias_v[n], g.relu);
+        if (obase) obase[orow * g.ldo + 32 * n] = v;
         cs[n] += v;
       }
     }
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
     __syncthreads();
     if (tid < BN) {
       const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * gridDim.x + blockIdx.x) * BN + tid] = s;
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * BN + tid] = s;
     }
   }
 }
@@ -284,9 +298,11 @@ __global__ void k_dense_naive(const float* __restrict__ x, int64_t rows, int k,
   out[idx] = activate(s, relu);
 }
 
-int launch_gemm(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
+int launch_gemm(GemmArgs g, int nt, int64_t batch, hipStream_t stream) {
   if (g.n_rows == 0 || batch == 0) return GUNET_OK;
+  if (g.out_rows == 0) g.out_rows = g.n_rows;
   dim3 grid(static_cast<unsigned>(ceil_div(g.n_rows, kBM)), static_cast<unsigned>(batch));
+  if (g.colsum != nullptr && g.colsum_tiles == 0) g.colsum_tiles = static_cast<int>(grid.x);
   ProfScope prof(kProfGemm, stream);
   switch (nt) {
     case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(g); break;
@@ -337,7 +353,8 @@ __device__ inline float combine_groups(const float* part, int col) {
 // thread groups by k (k = group, group + 8, ...) and the 8 partials are added in group order.
 __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
                                                                   const float* __restrict__ global_in,
-                                                                  int relu, float* __restrict__ nbias,
+                                                                  int relu, int fold_receiver,
+                                                                  float* __restrict__ nbias,
                                                                   float* __restrict__ ebias,
                                                                   float* __restrict__ gbias) {
   extern __shared__ float sh[];
@@ -381,6 +398,14 @@ __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
     float e = 0.0f;
     for (int k = 0; k < kU; ++k) e = fmaf(gq[q * kU + k], w[k * kU + j], e);
     if (p.edge_b[q]) e += p.edge_b[q][j];
+    if (fold_receiver) {
+      // every receiver is a zero input row: its embedding is act(bias), a constant of the layer
+      const float* wr = p.edge_w[q] + static_cast<int64_t>(p.f_e + kU) * kU;
+      float r = 0.0f;
+      for (int k = 0; k < kU; ++k)
+        r = fmaf(activate(p.node_emb_b[q] ? p.node_emb_b[q][k] : 0.0f, relu), wr[k * kU + j], r);
+      e += r;
+    }
     ebias[b * kUnits + tid] = e;
     if (b == 0) nbias[tid] = p.node_emb_b[q] ? p.node_emb_b[q][j] : 0.0f;
   }
@@ -398,15 +423,17 @@ struct EdgeArgs {
   const float* ebias;       // [B, 4, 32]
   float* partial;           // [B, 4, gridDim.x, 32] column sums of the messages
   int relu;
+  int sender_only;          // receivers contribute through the bias (graph upsampling)
+  float out_scale;          // stored message = out_scale * message (the column sums stay unscaled)
 };
 
 // Edge MLP for 32 edges per wave step: the A operand row of edge e is
 // [edge features | embedding of the sender | embedding of the receiver], gathered straight into
 // registers as float4 pieces (half-wave h takes floats 8c+4h..8c+4h+3 of every 8-float chunk);
 // the matching weight rows stay in registers for the whole workgroup.
-template <int FE_CHUNKS, bool FE_VEC>
+template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
 __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
-  constexpr int CH = FE_CHUNKS + 8;
+  constexpr int CH = FE_CHUNKS + (SENDER_ONLY ? 4 : 8);
   __shared__ float red[4 * kU];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         av[FE_CHUNKS + c] = ps[2 * c];
-        av[FE_CHUNKS + 4 + c] = pr[2 * c];
+        if (!SENDER_ONLY) av[FE_CHUNKS + 4 + c] = pr[2 * c];
       }
       f32x16 acc;
 #pragma unroll
@@ -486,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
         const int64_t row = e0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float v = activate(acc[r] + bias, a.relu);
         if (row < n_edges) {
-          out[row * kU + li] = v;
+          out[row * kU + li] = v * a.out_scale;
           colsum += v;
         }
       }
@@ -609,8 +636,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct LayerWorkspace {
-  float* xq;      // [B, N, 128]
-  float* agg;     // [B, N, 128]
+  float* xq;      // [B, N, 128]            node embeddings (generic) / coarse rows only (upsample)
+  float* agg;     // [B, N, 128]            aggregated messages (generic) / messages [B, N_fine, 32]
   float* nbias;   // [128]
   float* ebias;   // [B, 128]
   float* gbias;   // [B, 128]
@@ -620,6 +647,8 @@ struct LayerWorkspace {
   size_t bytes;
 };
 
+// One layout serves both entry points: the upsampling form needs at most 4 node tiles more than
+// the generic one (one partly filled tile per quadrant) and less of everything else.
 LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, void* base) {
   LayerWorkspace ws;
   const size_t n = static_cast<size_t>(g->n_nodes), bsz = static_cast<size_t>(batch);
@@ -638,10 +667,129 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, void* ba
   ws.nbias = take(kUnits);
   ws.ebias = take(bsz * kUnits);
   ws.gbias = take(bsz * kUnits);
-  ws.npart = take(bsz * ws.n_nblk * kUnits);
+  ws.npart = take(bsz * (ws.n_nblk + 5) * kUnits);
   ws.epart = take(bsz * 4 * ws.n_eblk * kU);
   ws.bytes = off;
   return ws;
+}
+
+int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch,
+                     int32_t activation, const void* workspace, size_t workspace_bytes, LayerWorkspace* ws) {
+  GUNET_REQUIRE(graph && w, "%s: null graph or weights", fn);
+  GUNET_REQUIRE(batch > 0, "%s: batch must be positive", fn);
+  GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU, "%s: unknown activation %d",
+                fn, activation);
+  if (w->units != kUnits) {
+    set_error("%s: units = %d is not implemented (only %d)", fn, w->units, kUnits);
+    return GUNET_ERR_UNSUPPORTED;
+  }
+  GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0, "%s: c_in = %d must be a positive multiple of 4", fn, w->c_in);
+  GUNET_REQUIRE(w->g > 0 && w->g <= 4096, "%s: global width %d outside 1..4096", fn, w->g);
+  if (w->f_e < 0 || w->f_e > 64) {
+    set_error("%s: edge feature width %d outside 0..64 is not implemented", fn, w->f_e);
+    return GUNET_ERR_UNSUPPORTED;
+  }
+  GUNET_REQUIRE(graph->n_nodes >= 0, "%s: negative node count", fn);
+  GUNET_REQUIRE(w->node_w, "%s: node_transform kernel is null", fn);
+  for (int q = 0; q < 4; ++q) {
+    GUNET_REQUIRE(graph->n_edges[q] >= 0, "%s: negative edge count", fn);
+    GUNET_REQUIRE(w->node_emb_w[q] && w->edge_w[q] && w->glob_w[q], "%s: null kernel for direction %d", fn, q);
+    if (graph->n_edges[q] > 0)
+      GUNET_REQUIRE(graph->edge_index[q] && graph->perm[q], "%s: null edge list for direction %d", fn, q);
+    GUNET_REQUIRE(graph->n_nodes == 0 || graph->rowptr[q], "%s: null rowptr for direction %d", fn, q);
+  }
+  *ws = carve_workspace(graph, batch, const_cast<void*>(workspace));
+  if (workspace == nullptr || workspace_bytes < ws->bytes) {
+    set_error("%s: workspace of %zu bytes is smaller than the %zu required", fn, workspace_bytes, ws->bytes);
+    return GUNET_ERR_WORKSPACE;
+  }
+  GUNET_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "%s: workspace must be 16-byte aligned", fn);
+  return GUNET_OK;
+}
+
+LayerPtrs layer_ptrs(const gunet_gn_weights* w) {
+  LayerPtrs p;
+  for (int q = 0; q < 4; ++q) {
+    p.node_emb_b[q] = w->node_emb_b[q];
+    p.edge_w[q] = w->edge_w[q];
+    p.edge_b[q] = w->edge_b[q];
+    p.glob_w[q] = w->glob_w[q];
+    p.glob_b[q] = w->glob_b[q];
+  }
+  p.node_w = w->node_w;
+  p.node_b = w->node_b;
+  p.globt_w = w->globt_w;
+  p.globt_b = w->globt_b;
+  p.c_in = w->c_in;
+  p.f_e = w->f_e;
+  p.g = w->g;
+  p.gsn = w->global_scale_nodes;
+  p.gse = w->global_scale_edges;
+  return p;
+}
+
+int launch_prologue(const LayerPtrs& p, const float* global_in, int relu, int fold_receiver, int32_t batch,
+                    const LayerWorkspace& ws, hipStream_t stream) {
+  ProfScope prof(kProfPrologue, stream);
+  k_layer_prologue<<<batch, kSmallThreads, sizeof(float) * (p.g + 4 * kU + kGroups * kUnits), stream>>>(
+      p, global_in, relu, fold_receiver, ws.nbias, ws.ebias, ws.gbias);
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+int launch_global_update(const LayerPtrs& p, const float* global_in, int n_nblk, int relu, int32_t batch,
+                         const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
+  ProfScope prof(kProfGlobalUpdate, stream);
+  k_global_update<<<batch, kSmallThreads,
+                    sizeof(double) * kGroups * kUnits + sizeof(float) * (kGroups * kUnits + p.g + kUnits + kU),
+                    stream>>>(p, global_in, ws.npart, n_nblk, ws.epart, ws.n_eblk, relu, global_out);
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+int launch_edge_mlp(EdgeArgs& a, const gunet_quadgraph* graph, const float* const edges[4], int n_eblk,
+                    int32_t batch, hipStream_t stream) {
+  bool any_feat = false, all_feat = true, vec_ok = a.f_e % 8 == 0;
+  for (int q = 0; q < 4; ++q) {
+    a.edge_index[q] = graph->edge_index[q];
+    a.efeat[q] = edges ? edges[q] : nullptr;
+    a.n_edges[q] = graph->n_edges[q];
+    if (graph->n_edges[q] > 0) {
+      if (a.efeat[q] != nullptr) {
+        any_feat = true;
+        if (reinterpret_cast<uintptr_t>(a.efeat[q]) % 16 != 0) vec_ok = false;
+      } else {
+        all_feat = false;
+      }
+    }
+  }
+  // a direction whose features are absent reads nothing; the vector loader needs all of them
+  dim3 grid(static_cast<unsigned>(n_eblk), 4, static_cast<unsigned>(batch));
+  ProfScope prof(kProfEdgeMlp, stream);
+  const int chunks = (!any_feat || a.f_e == 0) ? 0 : (a.f_e + 7) / 8;
+  if (a.sender_only) {
+    if (chunks != 0) {
+      set_error("edge_mlp: the sender-only form takes no edge features");
+      return GUNET_ERR_INVALID;
+    }
+    k_edge_mlp<0, false, true><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks == 0) {
+    k_edge_mlp<0, false, false><<<grid, kThreads, 0, stream>>>(a);
+  } else if (vec_ok && all_feat && chunks == 2) {
+    k_edge_mlp<2, true, false><<<grid, kThreads, 0, stream>>>(a);
+  } else if (vec_ok && all_feat && chunks == 4) {
+    k_edge_mlp<4, true, false><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks == 1) {
+    k_edge_mlp<1, false, false><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks == 2) {
+    k_edge_mlp<2, false, false><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks <= 4) {
+    k_edge_mlp<4, false, false><<<grid, kThreads, 0, stream>>>(a);
+  } else {
+    k_edge_mlp<8, false, false><<<grid, kThreads, 0, stream>>>(a);
+  }
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
 }
 
 }  // namespace
@@ -722,11 +870,9 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
     for (int t = 0; t < nt; ++t) g.seg[0].w[t] = kernel + col0 + 32 * t;
     g.n_rows = static_cast<int>(rows);
     g.bias = bias ? bias + col0 : nullptr;
-    g.bias_stride = 0;
     g.out = out;
     g.ldo = n_out;
     g.out_col0 = col0;
-    g.colsum = nullptr;
     g.relu = activation == GUNET_ACT_RELU;
     GUNET_TRY(launch_gemm(g, nt, 1, stream));
   }
@@ -738,85 +884,46 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
   return carve_workspace(graph, batch, nullptr).bytes;
 }
 
-int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* w,
-                               int32_t batch, const float* x, const float* const edges[4],
-                               const float* global_in, int32_t activation, float* x_out,
-                               float* const edges_out[4], float* global_out, void* workspace,
-                               size_t workspace_bytes, gunet_stream_t stream_) {
+int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch,
+                               const float* x, const float* x_skip, int32_t c_skip,
+                               const float* const edges[4], const float* global_in, int32_t activation,
+                               float* x_out, float* const edges_out[4], float* global_out,
+                               void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
   hipStream_t stream = as_stream(stream_);
-  GUNET_REQUIRE(graph && w, "gn_layer: null graph or weights");
-  GUNET_REQUIRE(batch > 0, "gn_layer: batch must be positive");
-  GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU,
-                "gn_layer: unknown activation %d", activation);
-  if (w->units != kUnits) {
-    set_error("gn_layer: units = %d is not implemented (only %d)", w->units, kUnits);
-    return GUNET_ERR_UNSUPPORTED;
-  }
-  GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0, "gn_layer: c_in = %d must be a positive multiple of 4", w->c_in);
-  GUNET_REQUIRE(w->g > 0 && w->g <= 4096, "gn_layer: global width %d outside 1..4096", w->g);
-  if (w->f_e < 0 || w->f_e > 64) {
-    set_error("gn_layer: edge feature width %d outside 0..64 is not implemented", w->f_e);
-    return GUNET_ERR_UNSUPPORTED;
-  }
-  GUNET_REQUIRE(graph->n_nodes >= 0, "gn_layer: negative node count");
+  LayerWorkspace ws;
+  GUNET_TRY(check_layer_args("gn_layer", graph, w, batch, activation, workspace, workspace_bytes, &ws));
   GUNET_REQUIRE(x && global_in && x_out && global_out && edges && edges_out, "gn_layer: null tensor");
-  GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0,
-                "gn_layer: x and x_out must be 16-byte aligned");
-  GUNET_REQUIRE(w->node_w, "gn_layer: node_transform kernel is null");
-  for (int q = 0; q < 4; ++q) {
-    GUNET_REQUIRE(graph->n_edges[q] >= 0, "gn_layer: negative edge count");
-    GUNET_REQUIRE(w->node_emb_w[q] && w->edge_w[q] && w->glob_w[q], "gn_layer: null kernel for direction %d", q);
-    if (graph->n_edges[q] > 0) {
-      GUNET_REQUIRE(graph->edge_index[q] && graph->perm[q] && edges_out[q],
-                    "gn_layer: null edge tensor for direction %d", q);
-    }
-    GUNET_REQUIRE(graph->n_nodes == 0 || graph->rowptr[q], "gn_layer: null rowptr for direction %d", q);
-  }
-  const LayerWorkspace ws = carve_workspace(graph, batch, workspace);
-  if (workspace == nullptr || workspace_bytes < ws.bytes) {
-    set_error("gn_layer: workspace of %zu bytes is smaller than the %zu required", workspace_bytes, ws.bytes);
-    return GUNET_ERR_WORKSPACE;
-  }
-  GUNET_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "gn_layer: workspace must be 16-byte aligned");
+  GUNET_REQUIRE(c_skip >= 0 && c_skip % 4 == 0 && c_skip < w->c_in && (c_skip == 0) == (x_skip == nullptr),
+                "gn_layer: bad skip segment (c_skip = %d of c_in = %d)", c_skip, w->c_in);
+  GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(x_skip) % 16 == 0,
+                "gn_layer: x, x_skip and x_out must be 16-byte aligned");
+  for (int q = 0; q < 4; ++q)
+    GUNET_REQUIRE(graph->n_edges[q] == 0 || edges_out[q], "gn_layer: null edges_out[%d]", q);
   const int relu = activation == GUNET_ACT_RELU;
   const int n = graph->n_nodes;
+  const int c_a = w->c_in - c_skip;          // width of x; x_skip supplies the remaining columns
+  const LayerPtrs p = layer_ptrs(w);
 
-  LayerPtrs p;
-  for (int q = 0; q < 4; ++q) {
-    p.node_emb_b[q] = w->node_emb_b[q];
-    p.edge_w[q] = w->edge_w[q];
-    p.edge_b[q] = w->edge_b[q];
-    p.glob_w[q] = w->glob_w[q];
-    p.glob_b[q] = w->glob_b[q];
-  }
-  p.node_w = w->node_w;
-  p.node_b = w->node_b;
-  p.globt_w = w->globt_w;
-  p.globt_b = w->globt_b;
-  p.c_in = w->c_in;
-  p.f_e = w->f_e;
-  p.g = w->g;
-  p.gsn = w->global_scale_nodes;
-  p.gse = w->global_scale_edges;
-
-  {
-    ProfScope prof(kProfPrologue, stream);
-    k_layer_prologue<<<batch, kSmallThreads, sizeof(float) * (w->g + 4 * kU + kGroups * kUnits), stream>>>(p, global_in, relu, ws.nbias,
-                                                                              ws.ebias, ws.gbias);
-    GUNET_LAUNCH_CHECK();
-  }
+  GUNET_TRY(launch_prologue(p, global_in, relu, 0, batch, ws, stream));
 
   {  // node embeddings of the four directions in one GEMM (hybrid_gnn.py:91-92)
     GemmArgs g = {};
-    g.n_seg = 1;
+    g.n_seg = c_skip ? 2 : 1;
     g.seg[0].a = x;
-    g.seg[0].lda = w->c_in;
-    g.seg[0].k = w->c_in;
+    g.seg[0].lda = c_a;
+    g.seg[0].k = c_a;
     g.seg[0].ldw = kU;
-    for (int q = 0; q < 4; ++q) g.seg[0].w[q] = w->node_emb_w[q];
+    g.seg[1].a = x_skip;
+    g.seg[1].lda = c_skip;
+    g.seg[1].k = c_skip;
+    g.seg[1].ldw = kU;
+    for (int q = 0; q < 4; ++q) {
+      g.seg[0].w[q] = w->node_emb_w[q];
+      g.seg[1].w[q] = w->node_emb_w[q] + static_cast<int64_t>(c_a) * kU;
+    }
     g.n_rows = n;
     g.bias = ws.nbias;
-    g.bias_stride = 0;
     g.out = ws.xq;
     g.ldo = kUnits;
     g.relu = relu;
@@ -824,18 +931,10 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
   }
 
   {  // edge MLP + message column sums (hybrid_gnn.py:93-108)
-    EdgeArgs a;
-    bool any_feat = false, vec_ok = w->f_e % 8 == 0;
+    EdgeArgs a = {};
     for (int q = 0; q < 4; ++q) {
-      a.edge_index[q] = graph->edge_index[q];
-      a.efeat[q] = edges[q];
       a.edge_w[q] = w->edge_w[q];
       a.out[q] = edges_out[q];
-      a.n_edges[q] = graph->n_edges[q];
-      if (graph->n_edges[q] > 0 && edges[q] != nullptr) {
-        any_feat = true;
-        if (reinterpret_cast<uintptr_t>(edges[q]) % 16 != 0) vec_ok = false;
-      }
     }
     a.n_nodes = n;
     a.f_e = w->f_e;
@@ -843,30 +942,8 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     a.ebias = ws.ebias;
     a.partial = ws.epart;
     a.relu = relu;
-    // a direction whose features are absent reads nothing; with vector loads every direction
-    // must have them, otherwise fall back to the guarded scalar loader
-    bool all_feat = true;
-    for (int q = 0; q < 4; ++q)
-      if (graph->n_edges[q] > 0 && edges[q] == nullptr) all_feat = false;
-    dim3 grid(static_cast<unsigned>(ws.n_eblk), 4, static_cast<unsigned>(batch));
-    ProfScope prof(kProfEdgeMlp, stream);
-    const int chunks = (!any_feat || w->f_e == 0) ? 0 : (w->f_e + 7) / 8;
-    if (chunks == 0) {
-      k_edge_mlp<0, false><<<grid, kThreads, 0, stream>>>(a);
-    } else if (vec_ok && all_feat && chunks == 2) {
-      k_edge_mlp<2, true><<<grid, kThreads, 0, stream>>>(a);
-    } else if (vec_ok && all_feat && chunks == 4) {
-      k_edge_mlp<4, true><<<grid, kThreads, 0, stream>>>(a);
-    } else if (chunks == 1) {
-      k_edge_mlp<1, false><<<grid, kThreads, 0, stream>>>(a);
-    } else if (chunks == 2) {
-      k_edge_mlp<2, false><<<grid, kThreads, 0, stream>>>(a);
-    } else if (chunks <= 4) {
-      k_edge_mlp<4, false><<<grid, kThreads, 0, stream>>>(a);
-    } else {
-      k_edge_mlp<8, false><<<grid, kThreads, 0, stream>>>(a);
-    }
-    GUNET_LAUNCH_CHECK();
+    a.out_scale = 1.0f;
+    GUNET_TRY(launch_edge_mlp(a, graph, edges, ws.n_eblk, batch, stream));
   }
 
   if (n > 0) {  // neighbour aggregation (hybrid_gnn.py:110-113)
@@ -886,21 +963,28 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_LAUNCH_CHECK();
   }
 
-  {  // node MLP over [x | aggregated messages], global columns folded into the bias (:118-126)
+  {  // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
     GemmArgs g = {};
-    g.n_seg = 2;
-    g.seg[0].a = x;
-    g.seg[0].lda = w->c_in;
-    g.seg[0].k = w->c_in;
-    g.seg[0].ldw = kUnits;
-    g.seg[1].a = ws.agg;
-    g.seg[1].lda = kUnits;
-    g.seg[1].k = kUnits;
-    g.seg[1].ldw = kUnits;
-    for (int t = 0; t < 4; ++t) {
-      g.seg[0].w[t] = w->node_w + 32 * t;
-      g.seg[1].w[t] = w->node_w + static_cast<int64_t>(w->c_in) * kUnits + 32 * t;
+    int s = 0;
+    g.seg[s].a = x;
+    g.seg[s].lda = c_a;
+    g.seg[s].k = c_a;
+    for (int t = 0; t < 4; ++t) g.seg[s].w[t] = w->node_w + 32 * t;
+    ++s;
+    if (c_skip) {
+      g.seg[s].a = x_skip;
+      g.seg[s].lda = c_skip;
+      g.seg[s].k = c_skip;
+      for (int t = 0; t < 4; ++t) g.seg[s].w[t] = w->node_w + static_cast<int64_t>(c_a) * kUnits + 32 * t;
+      ++s;
     }
+    g.seg[s].a = ws.agg;
+    g.seg[s].lda = kUnits;
+    g.seg[s].k = kUnits;
+    for (int t = 0; t < 4; ++t) g.seg[s].w[t] = w->node_w + static_cast<int64_t>(w->c_in) * kUnits + 32 * t;
+    ++s;
+    g.n_seg = s;
+    for (int i = 0; i < s; ++i) g.seg[i].ldw = kUnits;
     g.n_rows = n;
     g.bias = ws.gbias;
     g.bias_stride = kUnits;
@@ -911,14 +995,128 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_TRY(launch_gemm(g, 4, batch, stream));
   }
 
-  {
-    ProfScope prof(kProfGlobalUpdate, stream);
-    k_global_update<<<batch, kSmallThreads,
-                      sizeof(double) * kGroups * kUnits + sizeof(float) * (kGroups * kUnits + w->g + kUnits + kU), stream>>>(
-        p, global_in, ws.npart, n > 0 ? ws.n_nblk : 0, ws.epart, ws.n_eblk, relu, global_out);
-    GUNET_LAUNCH_CHECK();
+  return launch_global_update(p, global_in, n > 0 ? ws.n_nblk : 0, relu, batch, ws, global_out, stream);
+}
+
+int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w,
+                                  int32_t batch, const float* x, const float* global_in, int32_t activation,
+                                  float* x_out, float* global_out, void* workspace, size_t workspace_bytes,
+                                  gunet_stream_t stream_) {
+  hipStream_t stream = as_stream(stream_);
+  LayerWorkspace ws;
+  GUNET_TRY(check_layer_args("gn_upsample", graph, w, batch, activation, workspace, workspace_bytes, &ws));
+  GUNET_REQUIRE(x && global_in && x_out && global_out, "gn_upsample: null tensor");
+  GUNET_REQUIRE(n_coarse >= 0 && n_coarse <= graph->n_nodes, "gn_upsample: bad n_coarse");
+  const int n_fine = graph->n_nodes - n_coarse;
+  int64_t n_edges = 0;
+  for (int q = 0; q < 4; ++q) n_edges += graph->n_edges[q];
+  GUNET_REQUIRE(n_edges == n_fine,
+                "gn_upsample: %lld edges for %d fine nodes (every fine node needs exactly one parent edge)",
+                static_cast<long long>(n_edges), n_fine);
+  GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0,
+                "gn_upsample: x and x_out must be 16-byte aligned");
+  const int relu = activation == GUNET_ACT_RELU;
+  const LayerPtrs p = layer_ptrs(w);
+
+  // The layer input is [x ; 0]: rows n_coarse.. are zero, so their embedding is act(bias) for every
+  // fine node; its product with the receiver rows of the edge kernel is folded into the edge bias.
+  GUNET_TRY(launch_prologue(p, global_in, relu, 1, batch, ws, stream));
+
+  {  // embeddings of the coarse rows only
+    GemmArgs g = {};
+    g.n_seg = 1;
+    g.seg[0].a = x;
+    g.seg[0].lda = w->c_in;
+    g.seg[0].k = w->c_in;
+    g.seg[0].ldw = kU;
+    for (int q = 0; q < 4; ++q) g.seg[0].w[q] = w->node_emb_w[q];
+    g.n_rows = n_coarse;
+    g.bias = ws.nbias;
+    g.out = ws.xq;
+    g.ldo = kUnits;
+    g.relu = relu;
+    GUNET_TRY(launch_gemm(g, 4, batch, stream));
   }
-  return GUNET_OK;
+
+  // messages: every edge goes (coarse parent -> fine node); edge features are zero.  Stored
+  // already scaled by 1/4, quadrant after quadrant, in ws.agg viewed as [B, n_fine, 32].
+  float* msg[4];
+  {
+    int64_t off = 0;
+    EdgeArgs a = {};
+    for (int q = 0; q < 4; ++q) {
+      msg[q] = ws.agg + off;
+      off += static_cast<int64_t>(batch) * graph->n_edges[q] * kU;
+      a.edge_w[q] = w->edge_w[q];
+      a.out[q] = msg[q];
+    }
+    a.n_nodes = n_coarse;
+    a.f_e = w->f_e;
+    a.xq = ws.xq;
+    a.ebias = ws.ebias;
+    a.partial = ws.epart;
+    a.relu = relu;
+    a.sender_only = 1;
+    a.out_scale = 1.0f / (3 + 1);
+    GUNET_TRY(launch_edge_mlp(a, graph, nullptr, ws.n_eblk, batch, stream));
+  }
+
+  // node MLP.  Coarse rows: only the x columns are non-zero and only their column sums are used
+  // (the rows themselves are dropped by the caller, hybrid_gnn.py:377).  Fine rows: x is zero and
+  // the aggregate is the single incoming message in the columns of its quadrant, so each
+  // quadrant's edges are one K=32 GEMM scattered to the fine rows.
+  const int tiles_c = static_cast<int>(ceil_div(n_coarse, kBM));
+  int tiles_total = tiles_c;
+  int tile0[4];
+  for (int q = 0; q < 4; ++q) {
+    tile0[q] = tiles_total;
+    tiles_total += static_cast<int>(ceil_div(graph->n_edges[q], kBM));
+  }
+  if (n_coarse > 0) {
+    GemmArgs g = {};
+    g.n_seg = 1;
+    g.seg[0].a = x;
+    g.seg[0].lda = w->c_in;
+    g.seg[0].k = w->c_in;
+    g.seg[0].ldw = kUnits;
+    for (int t = 0; t < 4; ++t) g.seg[0].w[t] = w->node_w + 32 * t;
+    g.n_rows = n_coarse;
+    g.bias = ws.gbias;
+    g.bias_stride = kUnits;
+    g.out = nullptr;
+    g.ldo = kUnits;
+    g.colsum = ws.npart;
+    g.colsum_tiles = tiles_total;
+    g.colsum_tile0 = 0;
+    g.relu = relu;
+    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+  }
+  for (int q = 0; q < 4; ++q) {
+    if (graph->n_edges[q] == 0) continue;
+    GemmArgs g = {};
+    g.n_seg = 1;
+    g.seg[0].a = msg[q];
+    g.seg[0].lda = kU;
+    g.seg[0].k = kU;
+    g.seg[0].ldw = kUnits;
+    for (int t = 0; t < 4; ++t)
+      g.seg[0].w[t] = w->node_w + static_cast<int64_t>(w->c_in + kU * q) * kUnits + 32 * t;
+    g.n_rows = graph->n_edges[q];
+    g.bias = ws.gbias;
+    g.bias_stride = kUnits;
+    g.out = x_out;
+    g.ldo = kUnits;
+    g.out_rows = n_fine;
+    g.row_map = graph->edge_index[q] + 1;   // receiver column of the edge list
+    g.row_map_stride = 2;
+    g.row_map_sub = n_coarse;
+    g.colsum = ws.npart;
+    g.colsum_tiles = tiles_total;
+    g.colsum_tile0 = tile0[q];
+    g.relu = relu;
+    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+  }
+  return launch_global_update(p, global_in, tiles_total, relu, batch, ws, global_out, stream);
 }
 
 }  // extern "C"

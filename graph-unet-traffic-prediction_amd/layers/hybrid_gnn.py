@@ -204,16 +204,12 @@ class GeoQuadrantGCN:
 
     # -- forward ----------------------------------------------------------
     def call_concat(self, x, graph, training=False):
-        return self._forward(x, graph, zero_edges=False)
+        return self._forward(x, graph)
 
     call = call_concat
     __call__ = call_concat
 
-    def _forward(self, x, graph, zero_edges=False):
-        """zero_edges=True: the caller guarantees graph['edges'] is all zeros (graph
-        upsampling), so the edge-feature columns are skipped instead of read."""
-        edge_index = graph['edge_index']
-        edges = graph['edges']
+    def _prepare(self, x, graph):
         glob = graph['global']                      # KeyError when absent, like the reference (:83)
         if not self.use_global:
             raise NotImplementedError('GeoQuadrantGCN with use_global=False is not implemented; the '
@@ -223,10 +219,39 @@ class GeoQuadrantGCN:
         xb = x.unsqueeze(0) if single else x
         if xb.dim() != 3:
             raise ValueError(f'x must be [N, C] or [B, N, C], got {tuple(x.shape)}')
-        batch, n, c_in = xb.shape
         glob = _as_f32(glob, "graph['global']").reshape(-1, glob.shape[-1])
-        if glob.shape[0] != batch:
-            raise ValueError(f"graph['global'] has {glob.shape[0]} rows for a batch of {batch}")
+        if glob.shape[0] != xb.shape[0]:
+            raise ValueError(f"graph['global'] has {glob.shape[0]} rows for a batch of {xb.shape[0]}")
+        return xb, glob, single
+
+    def _outputs(self, batch, n_rows, g, device):
+        u = self.units // 4
+        x_out = torch.empty((batch, n_rows, self.units), dtype=torch.float32, device=device)
+        g_out = self.units if self.has_glob_transform else g + self.units + u
+        global_out = torch.empty((batch, g_out), dtype=torch.float32, device=device)
+        return x_out, global_out
+
+    def _scratch(self, qg, batch, device):
+        nbytes = qg.workspace_bytes(batch, self.units)
+        if nbytes == 0:
+            raise NotImplementedError(f'GeoQuadrantGCN with units={self.units} is not implemented.')
+        return _plan.workspace(nbytes, device)
+
+    def _forward(self, x, graph, x_skip=None):
+        """x_skip: optional trailing input columns, so that a caller need not materialise
+        concat(x, x_skip) (the up path, reference :235)."""
+        edge_index = graph['edge_index']
+        edges = graph['edges']
+        xb, glob, single = self._prepare(x, graph)
+        batch, n, c_a = xb.shape
+        c_skip = 0
+        if x_skip is not None:
+            x_skip = _as_f32(x_skip, 'x_skip')
+            x_skip = x_skip.unsqueeze(0) if x_skip.dim() == 2 else x_skip
+            if x_skip.shape[:2] != xb.shape[:2]:
+                raise ValueError(f'x_skip has shape {tuple(x_skip.shape)}, expected [{batch}, {n}, C]')
+            c_skip = x_skip.shape[2]
+        c_in = c_a + c_skip
         g = glob.shape[1]
         if len(edge_index) != 4 or len(edges) != 4:
             raise ValueError('GeoQuadrantGCN needs 4 edge lists and 4 edge-feature tensors')
@@ -247,26 +272,37 @@ class GeoQuadrantGCN:
         ws = self._weights_struct(c_in, f_e, g)
         u = self.units // 4
         dev = x.device
-        x_out = torch.empty((batch, n, self.units), dtype=torch.float32, device=dev)
+        x_out, global_out = self._outputs(batch, n, g, dev)
         edges_out = [torch.empty((batch, qg.n_edges[q], u), dtype=torch.float32, device=dev)
                      for q in range(4)]
-        g_out = self.units if self.has_glob_transform else g + self.units + u
-        global_out = torch.empty((batch, g_out), dtype=torch.float32, device=dev)
-        nbytes = qg.workspace_bytes(batch, self.units)
-        if nbytes == 0:
-            raise NotImplementedError(f'GeoQuadrantGCN with units={self.units} is not implemented.')
-        scratch = _plan.workspace(nbytes, dev)
-        in_ptrs = ptr4([None] * 4 if zero_edges else feats)
+        scratch = self._scratch(qg, batch, dev)
+        in_ptrs = ptr4(feats)
         out_ptrs = ptr4(edges_out)
-        call('gunet_gn_layer_forward_f32', C.byref(qg.struct), C.byref(ws), batch, ptr(xb),
-             C.byref(in_ptrs), ptr(glob), self._act, ptr(x_out), C.byref(out_ptrs), ptr(global_out),
-             ptr(scratch), scratch.numel(), current_stream(dev))
+        call('gunet_gn_layer_forward_f32', C.byref(qg.struct), C.byref(ws), batch, ptr(xb), ptr(x_skip),
+             c_skip, C.byref(in_ptrs), ptr(glob), self._act, ptr(x_out), C.byref(out_ptrs),
+             ptr(global_out), ptr(scratch), scratch.numel(), current_stream(dev))
         if single:
             x_out = x_out[0]
             edges_out = [e[0] for e in edges_out]
         graph['edges'] = edges_out                                          # :128
         graph['global'] = global_out                                        # :135
         return x_out, graph
+
+    def _upsample_forward(self, x, glob, up):
+        """The layer applied to [x ; zeros(n_fine)] on the upsampling graph `up` with zero edge
+        features, returning only the fine rows and the new global (reference :342-377)."""
+        xb, glob, single = self._prepare(x, {'global': glob})
+        batch, n_coarse, c_in = xb.shape
+        g = glob.shape[1]
+        self.build(c_in, 2, g, x.device)
+        ws = self._weights_struct(c_in, 2, g)
+        qg = up.quadgraph
+        x_out, global_out = self._outputs(batch, up.n_fine, g, x.device)
+        scratch = self._scratch(qg, batch, x.device)
+        call('gunet_gn_upsample_forward_f32', C.byref(qg.struct), n_coarse, C.byref(ws), batch, ptr(xb),
+             ptr(glob), self._act, ptr(x_out), ptr(global_out), ptr(scratch), scratch.numel(),
+             current_stream(x.device))
+        return (x_out[0] if single else x_out), global_out
 
 
 def _layer_class(layer_type, default):
@@ -342,8 +378,11 @@ class GraphUpsamplingBlock:
             raise NotImplementedError('diffuse_graph=True is not implemented (GraphUNet passes False).')
         x, graph = self.upsampling(x, graph, target_graph)
         x_res = x
-        x = torch.cat((x, x_skip), dim=-1)                                  # :235
-        for gcn in self.gcns:
+        if isinstance(self.gcns[0], GeoQuadrantGCN):
+            x, graph = self.gcns[0]._forward(x, graph, x_skip=x_skip)       # concat(x, x_skip) :235-237
+        else:
+            x, graph = self.gcns[0](torch.cat((x, x_skip), dim=-1), graph)
+        for gcn in self.gcns[1:]:
             x, graph = gcn(x, graph)
         if self.residual:
             x = x + x_res
@@ -376,20 +415,23 @@ class GraphUpsampling2x2:
         n_in = x.shape[-2]
         if n_in != up.n_coarse:
             raise ValueError(f'x has {n_in} rows but the coarse graph has {up.n_coarse} nodes')
-        zeros = torch.zeros(x.shape[:-2] + (up.n_fine, x.shape[-1]), dtype=x.dtype, device=x.device)
-        x = torch.cat((x, zeros), dim=-2)                                   # :342-344
-        lead = x.shape[:-2]
-        graph['edge_index'] = up.edge_index                                 # :371
-        graph['edges'] = [torch.zeros(lead + tuple(e.shape), dtype=torch.float32, device=x.device)
-                          for e in up.edge_index]                           # :373-374
-        graph['global'] = torch.cat((graph['global'].reshape(-1, graph['global'].shape[-1]),
-                                     target_graph['global'].reshape(-1, target_graph['global'].shape[-1])),
-                                    dim=-1)                                 # :375
-        if isinstance(self.gcn, GeoQuadrantGCN):
-            x, graph = self.gcn._forward(x, graph, zero_edges=True)         # :376
+        glob = torch.cat((graph['global'].reshape(-1, graph['global'].shape[-1]),
+                          target_graph['global'].reshape(-1, target_graph['global'].shape[-1])),
+                         dim=-1)                                            # :375
+        if isinstance(self.gcn, GeoQuadrantGCN) and sum(int(e.shape[0]) for e in up.edge_index) == up.n_fine:
+            # same result as the layer on [x ; zeros] with zero edge features (:342-377), without
+            # computing the zero rows
+            x, graph['global'] = self.gcn._upsample_forward(x, glob, up)
         else:
-            x, graph = self.gcn(x, graph)
-        x = x[..., n_in:, :]                                                # :377
+            zeros = torch.zeros(x.shape[:-2] + (up.n_fine, x.shape[-1]), dtype=x.dtype, device=x.device)
+            x = torch.cat((x, zeros), dim=-2)                               # :342-344
+            lead = x.shape[:-2]
+            graph['edge_index'] = up.edge_index                             # :371
+            graph['edges'] = [torch.zeros(lead + tuple(e.shape), dtype=torch.float32, device=x.device)
+                              for e in up.edge_index]                       # :373-374
+            graph['global'] = glob
+            x, graph = self.gcn(x, graph)                                   # :376
+            x = x[..., n_in:, :]                                            # :377
         graph['edge_index'] = target_graph['edge_index']                    # :382-384
         graph['edges'] = target_graph['edges']
         graph['node_loc'] = target_graph['node_loc']

@@ -10,6 +10,10 @@ edge-feature width F, global width G, U = 128 units, u = U / 4 (float32 = 4 byte
   aggregate bytes 4*(E*u + E + N*U)   read messages + read slot->edge map + write aggregates
   gather bytes    4*(2*E*u + 2*E)     the two row gathers feeding the edge MLP
   compulsory      4*(N*C + E*F + 2*E + E*u + N*U)
+The "*_executed" totals count what the kernels issue after the algebraic savings (global columns
+folded into biases; the upsampling layer computed without its zero rows); roofline fractions of
+the MFMA kernels use these, so they can never exceed 1, and the as-written totals are reported
+beside them.
 """
 
 U = 128
@@ -35,7 +39,7 @@ def layer_table(n_nodes, n_edges, f_e0=16, g0=113, in_features=104, out_units=96
     for d in range(depth):
         lvl = depth - 1 - d
         rows.append(dict(name=f'up{d}.upsample', kind='gn', n=n_nodes[lvl + 1] + n_nodes[lvl], e=n_nodes[lvl],
-                         c=U, f=2, g=U + skip_g[lvl]))
+                         c=U, f=2, g=U + skip_g[lvl], n_coarse=n_nodes[lvl + 1], n_fine=n_nodes[lvl]))
         rows.append(dict(name=f'up{d}.gcn0', kind='gn', n=n_nodes[lvl], e=n_edges[lvl], c=2 * U, f=skip_fe[lvl], g=U))
         rows.append(dict(name=f'up{d}.gcn1', kind='gn', n=n_nodes[lvl], e=n_edges[lvl], c=U, f=SMALL_U, g=U))
     rows.append(dict(name='out_model', kind='dense', n=n_nodes[0], k=U, out=out_units))
@@ -45,10 +49,12 @@ def layer_table(n_nodes, n_edges, f_e0=16, g0=113, in_features=104, out_units=96
 def work_per_sample(rows):
     """Totals for one sample: FLOPs per MFMA kernel class and bytes per HBM-bound class."""
     w = dict(gemm_flops=0.0, edge_flops=0.0, aggregate_bytes=0.0, gather_bytes=0.0, compulsory_bytes=0.0,
-             pool_bytes=0.0, gemm_launches=0, edge_launches=0, aggregate_launches=0)
+             pool_bytes=0.0, gemm_launches=0, edge_launches=0, aggregate_launches=0,
+             gemm_flops_executed=0.0, edge_flops_executed=0.0, aggregate_bytes_executed=0.0)
     for r in rows:
         if r['kind'] == 'dense':
             w['gemm_flops'] += 2.0 * r['n'] * r['k'] * r['out']
+            w['gemm_flops_executed'] += 2.0 * r['n'] * r['k'] * r['out']
             w['gemm_launches'] += 1
             w['compulsory_bytes'] += 4.0 * r['n'] * (r['k'] + r['out'])
         elif r['kind'] == 'gn':
@@ -61,9 +67,20 @@ def work_per_sample(rows):
             w['aggregate_launches'] += 1
             w['gather_bytes'] += 4.0 * (2 * e * SMALL_U + 2 * e)
             w['compulsory_bytes'] += 4.0 * (n * c + e * f + 2 * e + e * SMALL_U + n * U)
+            # what the kernels execute: the global columns are folded into biases, edge features
+            # are padded to a multiple of 8, and the upsampling layer skips its zero rows
+            if 'n_coarse' in r:
+                nc, nf = r['n_coarse'], r['n_fine']
+                w['gemm_flops_executed'] += 2.0 * nc * c * U * 2 + 2.0 * nf * SMALL_U * U
+                w['edge_flops_executed'] += 2.0 * e * SMALL_U * SMALL_U
+            else:
+                w['gemm_flops_executed'] += 2.0 * n * c * U + 2.0 * n * (c + U) * U
+                w['edge_flops_executed'] += 2.0 * e * (-(-f // 8) * 8 + 2 * SMALL_U) * SMALL_U
+                w['aggregate_bytes_executed'] += 4.0 * (e * SMALL_U + e + n * U)
         elif r['kind'] == 'pool':
             w['pool_bytes'] += 4.0 * (r['n'] * U + r['p'] * U) + 4.0 * (r['e'] * SMALL_U + r['e2'] * SMALL_U)
     w['total_flops'] = w['gemm_flops'] + w['edge_flops']
+    w['total_flops_executed'] = w['gemm_flops_executed'] + w['edge_flops_executed']
     return w
 
 

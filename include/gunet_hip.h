@@ -156,7 +156,9 @@ typedef struct gunet_gn_weights {
 size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batch, int32_t units);
 
 /* layers/hybrid_gnn.py:72-137 GeoQuadrantGCN.call_concat with use_global=True.
- *   x          [B, N, c_in]
+ *   x          [B, N, c_in - c_skip]
+ *   x_skip     [B, N, c_skip] or NULL (c_skip = 0): the trailing input columns, so that the caller of
+ *              the up path (hybrid_gnn.py:235, x = concat(x, x_skip)) need not materialise the concat
  *   edges[q]   [B, E_q, f_e], or NULL meaning all-zero edge features
  *   global_in  [B, g]
  *   x_out      [B, N, units]
@@ -164,10 +166,25 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
  *   global_out [B, units], or [B, g + units + u] when globt_w == NULL
  * Only units == 128 is implemented. */
 int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* weights,
-                               int32_t batch, const float* x, const float* const edges[4],
-                               const float* global_in, int32_t activation, float* x_out,
-                               float* const edges_out[4], float* global_out, void* workspace,
-                               size_t workspace_bytes, gunet_stream_t stream);
+                               int32_t batch, const float* x, const float* x_skip, int32_t c_skip,
+                               const float* const edges[4], const float* global_in,
+                               int32_t activation, float* x_out, float* const edges_out[4],
+                               float* global_out, void* workspace, size_t workspace_bytes,
+                               gunet_stream_t stream);
+
+/* layers/hybrid_gnn.py:336-378: the GN layer of GraphUpsampling2x2 (method 'graph').  The
+ * reference runs the layer above on [x ; zeros(n_fine)] with zero edge features and keeps the
+ * fine rows; this entry point returns the same fine rows and global without the zero rows:
+ * `graph` is the upsampling graph over n_coarse + n_fine nodes whose edges are
+ * (parent, n_coarse + i), exactly one per fine node (gunet_upsample_edges);
+ *   x [B, n_coarse, c_in], global_in [B, g] (already [global | target global]),
+ *   x_out [B, n_fine, units], global_out as above.  The layer's edge outputs are not returned
+ * (the reference discards them, :383).  Workspace: gunet_gn_layer_workspace_bytes(graph, ...). */
+int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse,
+                                  const gunet_gn_weights* weights, int32_t batch, const float* x,
+                                  const float* global_in, int32_t activation, float* x_out,
+                                  float* global_out, void* workspace, size_t workspace_bytes,
+                                  gunet_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3. Measurement -- no counterpart in the reference

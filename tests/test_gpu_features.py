@@ -232,3 +232,46 @@ def test_graph_unet_config2_road_graph(amd, oracle):
         want_y, want_g = oracle.predict(xs[b], copy_graph(graphs[b]), W)
         assert rel_err(got_y[b], want_y) <= TOL, b
         assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
+
+
+def test_graph_upsampling_layer(amd, oracle):
+    """GraphUpsampling2x2 (method 'graph') on its own: the zero-row-free kernel path against the
+    oracle's GN layer on [x ; zeros], single sample and batched."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(33, 41, 0.5, 13)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    rng = np.random.Generator(np.random.PCG64(14))
+    fine = {'node_loc': node_loc, 'edge_index': list(quads),
+            'edges': [rng.random((q.shape[0], 16)).astype(np.float32) for q in quads],
+            'global': rng.random((1, 113)).astype(np.float32)}
+    ids, p = oracle.cluster_ids_2x2(node_loc)
+    _, coarse = oracle.graph_pooling_2x2(np.zeros((node_loc.shape[0], 1), np.float32), copy_graph(fine))
+    coarse['edges'] = [rng.random((e.shape[0], 32)).astype(np.float32) for e in coarse['edge_index']]
+    coarse['global'] = rng.random((1, 128)).astype(np.float32)
+    x = (rng.random((p, 128)) - 0.2).astype(np.float32)
+    W = oracle.make_weights(oracle.gn_layer_shapes('U/gcn', 128, 2, 128 + 113), 3)
+    want_x, want_g = oracle.graph_upsampling_graph(x, copy_graph(coarse), fine, W, 'U')
+    up = amd.hybrid_gnn.GraphUpsampling2x2(128, method='graph', layer_type='geo_quadrant_gcn', use_global=True,
+                                           use_bias=True, activation='relu')
+    up.gcn.load_weights(W, 'U/gcn', 'cuda')
+    got_x, got_g = up(to_dev(x), graph_to_dev(coarse), graph_to_dev(fine))
+    assert tuple(got_x.shape) == want_x.shape
+    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    for q in range(4):                                  # the target graph's lists and features come back
+        assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), fine['edge_index'][q])
+        assert np.array_equal(got_g['edges'][q].cpu().numpy(), fine['edges'][q])
+    # generic path (the layer on [x ; zeros] with explicit zero edge features) gives the same numbers
+    upg = amd.plan.get_upsample_plan(to_dev(coarse['node_loc'], torch.int64), to_dev(node_loc, torch.int64))
+    xz = torch.cat((to_dev(x), torch.zeros((node_loc.shape[0], 128), device='cuda')))
+    gg = {'edge_index': upg.edge_index, 'edges': [torch.zeros((e.shape[0], 2), device='cuda') for e in upg.edge_index],
+          'global': torch.cat((to_dev(coarse['global']), to_dev(fine['global'])), dim=-1)}
+    gen_x, gen_g = up.gcn(xz, gg)
+    assert rel_err(got_x.cpu().numpy(), gen_x[p:].cpu().numpy()) <= 2e-6
+    assert rel_err(got_g['global'].cpu().numpy(), gen_g['global'].cpu().numpy()) <= 2e-6
+    # batched
+    cb, fb = graph_to_dev(coarse), graph_to_dev(fine)
+    cb['global'] = cb['global'].repeat(3, 1)
+    fb['global'] = fb['global'].repeat(3, 1)
+    bx, bg = up(to_dev(x).unsqueeze(0).repeat(3, 1, 1), cb, fb)
+    for b in range(3):
+        assert torch.equal(bx[b], got_x) and torch.equal(bg['global'][b], got_g['global'][0])
