@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-runs', type=int, default=3)
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel event pass')
+    ap.add_argument('--matmul', default=os.environ.get('GUNET_BENCH_MATMUL', 'f32'), choices=['f32', 'split3', 'split2', 'bf16'],
+                    help='matrix-product arithmetic (see gunet_set_matmul_mode)')
     return ap.parse_args()
 
 
@@ -86,6 +88,7 @@ def main():
 
     import gunet_amd
     from gunet_amd import synthetic, workload, sharding, _lib
+    gunet_amd.set_matmul_mode(args.matmul)
 
     # ---- workload -----------------------------------------------------------------------
     if args.dense:
@@ -219,7 +222,10 @@ def main():
     result = {
         'metric': 'GraphUNet fwd samples/sec (495x436 grid)', 'value': samples_per_s, 'unit': 'samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'f32': 'f32', 'split3': 'f32 (3xbf16-split operands, 6 bf16 MFMA products, f32 accumulate)',
+                  'split2': 'f32 storage, 2xbf16-split matmul', 'bf16': 'bf16 matmul, f32 storage/accumulate'}[args.matmul],
+        'data': 'synthetic',
         'config': {
             'workload': ('full GraphUNet fwd, checkpoint shapes (12x8-ch in, 12x8-ch out, width 128, depth 3), '
                          f'one {args.height}x{args.width} ' + ('dense grid' if args.dense else f'road graph (density {args.density}, seed 0)')

@@ -8,7 +8,7 @@ Layout mirrors the reference modules that lie on the path:
     models.graph_unet   GraphUNet
 """
 from . import _lib                                   # raises if libgunet_hip.so is missing
-from ._lib import GunetError, LIB_PATH
+from ._lib import GunetError, LIB_PATH, set_matmul_mode, get_matmul_mode
 from . import plan
 from . import layers
 from .layers import hybrid_gnn, graph_ops
@@ -16,5 +16,5 @@ from .data import data_utils
 from .models import graph_unet
 from .models.graph_unet import GraphUNet
 
-__all__ = ['GunetError', 'LIB_PATH', 'plan', 'layers', 'hybrid_gnn', 'graph_ops', 'data_utils',
+__all__ = ['GunetError', 'LIB_PATH', 'set_matmul_mode', 'get_matmul_mode', 'plan', 'layers', 'hybrid_gnn', 'graph_ops', 'data_utils',
            'graph_unet', 'GraphUNet']

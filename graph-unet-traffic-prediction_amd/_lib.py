@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'libgunet_hip.so')
 ACT_LINEAR = 0
 ACT_RELU = 1
 
+MATMUL_MODES = {'f32': 0, 'split3': 1, 'split2': 2, 'bf16': 3}
+
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 f32p = C.POINTER(C.c_float)
@@ -72,8 +74,12 @@ SIGNATURES = {
                                         C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'gunet_segment_sum_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    'gunet_set_matmul_mode': (C.c_int, [C.c_int]),
+    'gunet_get_matmul_mode': (C.c_int, []),
+    'gunet_dense_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'gunet_dense_forward_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
-                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p]),
     'gunet_gn_layer_workspace_bytes': (C.c_size_t, [C.POINTER(QuadGraphStruct), C.c_int32,
                                                     C.c_int32]),
     'gunet_gn_layer_forward_f32': (C.c_int, [C.POINTER(QuadGraphStruct),
@@ -146,3 +152,13 @@ def profile_collect():
     ms, n = F64xP(), I64xP()
     call('gunet_profile_collect', C.byref(ms), C.byref(n))
     return {lib.gunet_profile_class_name(c).decode(): (float(ms[c]), int(n[c])) for c in range(PROF_CLASSES)}
+
+
+def set_matmul_mode(mode):
+    """'f32' (exact float32 MFMA), 'split3' (float32-class on bf16 matrix cores), 'split2', 'bf16'."""
+    call('gunet_set_matmul_mode', MATMUL_MODES[mode] if isinstance(mode, str) else int(mode))
+
+
+def get_matmul_mode():
+    code = lib.gunet_get_matmul_mode()
+    return {v: k for k, v in MATMUL_MODES.items()}[code]

@@ -298,12 +298,278 @@ __global__ void k_dense_naive(const float* __restrict__ x, int64_t rows, int k,
   out[idx] = activate(s, relu);
 }
 
-int launch_gemm(GemmArgs g, int nt, int64_t batch, hipStream_t stream) {
+// ---------------------------------------------------------------- GEMM on bf16 MFMA with split operands
+
+// float32 products from bf16 matrix cores: every operand is written as a sum of SPL bf16 pieces
+// (x = x0 + x1 + x2, each piece the bf16 rounding of what the previous ones left), and the
+// product is the sum of the piece products whose weight is not below 2^-24 of the leading one:
+//   SPL 3: x0w0 + x0w1 + x1w0 + x0w2 + x1w1 + x2w0   (float32-class accuracy, 6 MFMAs)
+//   SPL 2: x0w0 + x0w1 + x1w0                        (about 2^-17 relative, 3 MFMAs)
+//   SPL 1: x0w0                                      (plain bf16 inputs, 1 MFMA)
+// all accumulated in float32 by v_mfma_f32_32x32x16_bf16, which runs 16x the rate of the float32
+// MFMA, so even the 6-term form needs 2.7x fewer matrix-core cycles than k_gemm_f32.
+// The weight pieces are prepared once per launch by k_pack_weights in the exact image the
+// workgroups copy into LDS: [k tile][piece][k step][half][column][8 consecutive k] bf16.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int SPL>
+struct Pieces {
+  bf16x8 p[SPL];
+};
+
+template <int SPL>
+__device__ inline Pieces<SPL> split_bf16(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                         float v7) {
+  Pieces<SPL> out;
+  const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r = v[j];
+    const __bf16 h0 = static_cast<__bf16>(r);
+    out.p[0][j] = h0;
+    if constexpr (SPL > 1) {
+      r -= static_cast<float>(h0);
+      const __bf16 h1 = static_cast<__bf16>(r);
+      out.p[1][j] = h1;
+      if constexpr (SPL > 2) {
+        r -= static_cast<float>(h1);
+        out.p[2][j] = static_cast<__bf16>(r);
+      }
+    }
+  }
+  return out;
+}
+
+struct PackArgs {
+  GemmSeg seg[3];
+  int n_seg;
+  int nt;        // column tiles of 32
+  uint4* out;    // [n_ktiles][SPL][2][2][32 * nt] groups of 8 bf16
+};
+
+template <int SPL>
+__global__ void k_pack_weights(PackArgs p) {
+  const int bn = 32 * p.nt;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (tile, kstep, half, column)
+  const int col = idx % bn;
+  idx /= bn;
+  const int half = idx & 1, kstep = (idx >> 1) & 1;
+  int tile = idx >> 2;
+  const int tile_id = tile;
+  int s = 0;
+  while (s < p.n_seg) {
+    const int nt = (p.seg[s].k + kBK - 1) / kBK;
+    if (tile < nt) break;
+    tile -= nt;
+    ++s;
+  }
+  if (s >= p.n_seg) return;
+  const GemmSeg& sg = p.seg[s];
+  const int k0 = tile * kBK + 16 * kstep + 8 * half;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    v[j] = (k0 + j < sg.k) ? sg.w[col >> 5][static_cast<int64_t>(k0 + j) * sg.ldw + (col & 31)] : 0.0f;
+  const Pieces<SPL> parts = split_bf16<SPL>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+  for (int t = 0; t < SPL; ++t)
+    p.out[((static_cast<int64_t>(tile_id) * SPL + t) * 4 + kstep * 2 + half) * bn + col] =
+        __builtin_bit_cast(uint4, parts.p[t]);
+}
+
+template <int NT, int SPL>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const uint4* __restrict__ wpack) {
+  constexpr int BN = 32 * NT;
+  constexpr int kTileVec = SPL * 4 * BN;                  // uint4 per K tile of the weight image
+  constexpr int kStage = (kTileVec + kThreads - 1) / kThreads;
+  __shared__ uint4 Bs[2][kTileVec];
+  __shared__ float red[4 * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.y;
+  const int row0 = blockIdx.x * kBM;
+  const int my_row = row0 + 32 * wave + li;
+  const bool row_ok = my_row < g.n_rows;
+
+  int n_tiles = 0;
+  for (int s = 0; s < g.n_seg; ++s) n_tiles += (g.seg[s].k + kBK - 1) / kBK;
+
+  auto locate = [&](int t, int& s, int& k0) {
+    s = 0;
+    while (true) {
+      const int nt = (g.seg[s].k + kBK - 1) / kBK;
+      if (t < nt) break;
+      t -= nt;
+      ++s;
+    }
+    k0 = t * kBK;
+  };
+  // lane (li, lh) owns row 32*wave+li and, per 16-wide k step s, floats 16s+8lh .. 16s+8lh+7
+  auto load_a = [&](int t, float4 (&a)[4]) {
+    int s, k0;
+    locate(t, s, k0);
+    const GemmSeg& sg = g.seg[s];
+    const float* p = sg.a + (b * g.n_rows + my_row) * static_cast<int64_t>(sg.lda) + k0 + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int off = 16 * (c >> 1) + 4 * (c & 1);
+      if (row_ok && k0 + 8 * lh + off < sg.k)
+        a[c] = *reinterpret_cast<const float4*>(p + off);
+      else
+        a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // the weight image is already in LDS order: a straight 16-byte-per-lane copy, global -> LDS
+  // without passing through registers (lane-linear destination, as global_load_lds requires)
+  auto stage_b = [&](int t, int buf) {
+    const uint4* src = wpack + static_cast<int64_t>(t) * kTileVec;
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) {
+      const int i = tid + kThreads * j;
+      if (kTileVec % kThreads == 0 || i < kTileVec)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + i),
+            (__attribute__((address_space(3))) void*)(&Bs[buf][i]), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[NT];
+  float bias_v[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * n + li] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+  }
+
+  float4 a_cur[4], a_nxt[4];
+  load_a(0, a_cur);
+  stage_b(0, 0);
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    const bool more = t + 1 < n_tiles;
+    if (more) {
+      stage_b(t + 1, (t + 1) & 1);
+      load_a(t + 1, a_nxt);
+    }
+    const uint4* bs = Bs[t & 1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const Pieces<SPL> apieces =
+          split_bf16<SPL>(a_cur[2 * s].x, a_cur[2 * s].y, a_cur[2 * s].z, a_cur[2 * s].w, a_cur[2 * s + 1].x,
+                          a_cur[2 * s + 1].y, a_cur[2 * s + 1].z, a_cur[2 * s + 1].w);
+      const bf16x8* ap = apieces.p;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bf16x8 wp[SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p)
+          wp[p] = __builtin_bit_cast(bf16x8, bs[(p * 4 + s * 2 + lh) * BN + 32 * n + li]);
+        // smallest terms first
+        if constexpr (SPL == 3) {
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], wp[0], acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], wp[1], acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], wp[2], acc[n], 0, 0, 0);
+        }
+        if constexpr (SPL >= 2) {
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], wp[0], acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], wp[1], acc[n], 0, 0, 0);
+        }
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], wp[0], acc[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // also retires the direct-to-LDS copy of the next weight tile
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
+  }
+
+  float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + g.out_col0 + li : nullptr;
+  float cs[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) cs[n] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (row < g.n_rows) {
+      const int64_t orow = g.row_map ? g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub : row;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float v = activate(acc[n][r] + bias_v[n], g.relu);
+        if (obase) obase[orow * g.ldo + 32 * n] = v;
+        cs[n] += v;
+      }
+    }
+  }
+  if (g.colsum != nullptr) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      cs[n] += __shfl_xor(cs[n], 32);
+      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * BN + tid] = s;
+    }
+  }
+}
+
+// Matmul arithmetic of the feature kernels (gunet_set_matmul_mode).
+int g_matmul_mode = GUNET_MATMUL_F32;
+
+inline int mode_pieces(int mode) {
+  return mode == GUNET_MATMUL_SPLIT3 ? 3 : mode == GUNET_MATMUL_SPLIT2 ? 2 : mode == GUNET_MATMUL_BF16 ? 1 : 0;
+}
+
+inline int gemm_ktiles(const GemmArgs& g) {
+  int n = 0;
+  for (int s = 0; s < g.n_seg; ++s) n += (g.seg[s].k + kBK - 1) / kBK;
+  return n;
+}
+
+// Bytes of weight image a launch of `ktiles` K tiles and `nt` column tiles needs in this mode.
+inline size_t wpack_bytes(int ktiles, int nt) {
+  return static_cast<size_t>(ktiles) * 3 * 4 * 32 * nt * sizeof(uint4);
+}
+
+template <int SPL>
+int launch_gemm_split(const GemmArgs& g, int nt, dim3 grid, uint4* wpack, hipStream_t stream) {
+  PackArgs p;
+  for (int s = 0; s < 3; ++s) p.seg[s] = g.seg[s];
+  p.n_seg = g.n_seg;
+  p.nt = nt;
+  p.out = wpack;
+  const int work = gemm_ktiles(g) * 4 * 32 * nt;
+  k_pack_weights<SPL><<<static_cast<unsigned>(ceil_div(work, kThreads)), kThreads, 0, stream>>>(p);
+  GUNET_LAUNCH_CHECK();
+  switch (nt) {
+    case 1: k_gemm_split<1, SPL><<<grid, kThreads, 0, stream>>>(g, wpack); break;
+    case 2: k_gemm_split<2, SPL><<<grid, kThreads, 0, stream>>>(g, wpack); break;
+    case 3: k_gemm_split<3, SPL><<<grid, kThreads, 0, stream>>>(g, wpack); break;
+    case 4: k_gemm_split<4, SPL><<<grid, kThreads, 0, stream>>>(g, wpack); break;
+    default: set_error("launch_gemm: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+  }
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+// wpack: scratch of at least wpack_bytes(gemm_ktiles(g), nt) for the split modes (may be null in
+// GUNET_MATMUL_F32 mode).
+int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stream) {
   if (g.n_rows == 0 || batch == 0) return GUNET_OK;
   if (g.out_rows == 0) g.out_rows = g.n_rows;
   dim3 grid(static_cast<unsigned>(ceil_div(g.n_rows, kBM)), static_cast<unsigned>(batch));
   if (g.colsum != nullptr && g.colsum_tiles == 0) g.colsum_tiles = static_cast<int>(grid.x);
   ProfScope prof(kProfGemm, stream);
+  const int pieces = mode_pieces(g_matmul_mode);
+  if (pieces > 0 && wpack != nullptr) {
+    uint4* wp = static_cast<uint4*>(wpack);
+    if (pieces == 3) return launch_gemm_split<3>(g, nt, grid, wp, stream);
+    if (pieces == 2) return launch_gemm_split<2>(g, nt, grid, wp, stream);
+    return launch_gemm_split<1>(g, nt, grid, wp, stream);
+  }
   switch (nt) {
     case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(g); break;
     case 2: k_gemm_f32<2><<<grid, kThreads, 0, stream>>>(g); break;
@@ -321,6 +587,8 @@ constexpr int kU = 32;           // per-direction width (units / 4)
 constexpr int kUnits = 128;
 constexpr int kEdgeGroups = 4;   // 32-edge groups per wave
 constexpr int kEdgesPerBlock = 4 * 32 * kEdgeGroups;
+constexpr int kMaxCin = 1024;                       // widest layer input the workspace is sized for
+constexpr int kMaxKTiles = kMaxCin / kBK + 2 + kUnits / kBK;
 
 struct LayerPtrs {
   const float* node_emb_b[4];
@@ -643,6 +911,7 @@ struct LayerWorkspace {
   float* gbias;   // [B, 128]
   float* npart;   // [B, n_nblk, 128]
   float* epart;   // [B, 4, n_eblk, 32]
+  void* wpack;    // weight image of the GEMM in flight (split-bf16 matmul modes)
   int n_nblk, n_eblk;
   size_t bytes;
 };
@@ -669,6 +938,7 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, void* ba
   ws.gbias = take(bsz * kUnits);
   ws.npart = take(bsz * (ws.n_nblk + 5) * kUnits);
   ws.epart = take(bsz * 4 * ws.n_eblk * kU);
+  ws.wpack = take(wpack_bytes(kMaxKTiles, 4) / sizeof(float));
   ws.bytes = off;
   return ws;
 }
@@ -683,7 +953,8 @@ int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_g
     set_error("%s: units = %d is not implemented (only %d)", fn, w->units, kUnits);
     return GUNET_ERR_UNSUPPORTED;
   }
-  GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0, "%s: c_in = %d must be a positive multiple of 4", fn, w->c_in);
+  GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0 && w->c_in <= kMaxCin,
+                "%s: c_in = %d must be a positive multiple of 4, at most %d", fn, w->c_in, kMaxCin);
   GUNET_REQUIRE(w->g > 0 && w->g <= 4096, "%s: global width %d outside 1..4096", fn, w->g);
   if (w->f_e < 0 || w->f_e > 64) {
     set_error("%s: edge feature width %d outside 0..64 is not implemented", fn, w->f_e);
@@ -839,9 +1110,14 @@ int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const 
                                       out, as_stream(stream));
 }
 
+size_t gunet_dense_workspace_bytes(int32_t k, int32_t n_out) {
+  if (k <= 0 || n_out <= 0) return 0;
+  return wpack_bytes(static_cast<int>(ceil_div(k, kBK)), 4) + 256;
+}
+
 int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float* kernel,
                             const float* bias, int32_t n_out, int32_t activation, float* out,
-                            gunet_stream_t stream_) {
+                            void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(rows >= 0 && k > 0 && n_out > 0, "dense_forward: bad shape");
   GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU,
@@ -859,6 +1135,16 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
     GUNET_LAUNCH_CHECK();
     return GUNET_OK;
   }
+  if (mode_pieces(g_matmul_mode) > 0) {
+    if (workspace == nullptr || workspace_bytes < gunet_dense_workspace_bytes(k, n_out) ||
+        reinterpret_cast<uintptr_t>(workspace) % 16 != 0) {
+      set_error("dense_forward: the split-bf16 matmul modes need a 16-byte aligned workspace of %zu bytes",
+                gunet_dense_workspace_bytes(k, n_out));
+      return GUNET_ERR_WORKSPACE;
+    }
+  } else {
+    workspace = nullptr;
+  }
   for (int col0 = 0; col0 < n_out; col0 += 128) {
     const int nt = (n_out - col0 >= 128) ? 4 : (n_out - col0) / 32;
     GemmArgs g = {};
@@ -874,10 +1160,20 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
     g.ldo = n_out;
     g.out_col0 = col0;
     g.relu = activation == GUNET_ACT_RELU;
-    GUNET_TRY(launch_gemm(g, nt, 1, stream));
+    GUNET_TRY(launch_gemm(g, nt, 1, workspace, stream));
   }
   return GUNET_OK;
 }
+
+int gunet_set_matmul_mode(int mode) {
+  GUNET_REQUIRE(mode == GUNET_MATMUL_F32 || mode == GUNET_MATMUL_SPLIT3 || mode == GUNET_MATMUL_SPLIT2 ||
+                    mode == GUNET_MATMUL_BF16,
+                "set_matmul_mode: unknown mode %d", mode);
+  g_matmul_mode = mode;
+  return GUNET_OK;
+}
+
+int gunet_get_matmul_mode(void) { return g_matmul_mode; }
 
 size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batch, int32_t units) {
   if (graph == nullptr || batch <= 0 || units != kUnits) return 0;
@@ -927,7 +1223,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     g.out = ws.xq;
     g.ldo = kUnits;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
   }
 
   {  // edge MLP + message column sums (hybrid_gnn.py:93-108)
@@ -992,7 +1288,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     g.ldo = kUnits;
     g.colsum = ws.npart;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
   }
 
   return launch_global_update(p, global_in, n > 0 ? ws.n_nblk : 0, relu, batch, ws, global_out, stream);
@@ -1035,7 +1331,7 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     g.out = ws.xq;
     g.ldo = kUnits;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
   }
 
   // messages: every edge goes (coarse parent -> fine node); edge features are zero.  Stored
@@ -1089,7 +1385,7 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     g.colsum_tiles = tiles_total;
     g.colsum_tile0 = 0;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
   }
   for (int q = 0; q < 4; ++q) {
     if (graph->n_edges[q] == 0) continue;
@@ -1114,7 +1410,7 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     g.colsum_tiles = tiles_total;
     g.colsum_tile0 = tile0[q];
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, stream));
+    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
   }
   return launch_global_update(p, global_in, tiles_total, relu, batch, ws, global_out, stream);
 }

@@ -82,8 +82,9 @@ class Dense:
             raise ValueError(f'Dense expects {self.kernel.shape[0]} input features, got {x.shape[-1]}')
         rows = x.numel() // x.shape[-1]
         out = torch.empty(x.shape[:-1] + (self.units,), dtype=torch.float32, device=x.device)
+        scratch = _plan.workspace(_lib.lib.gunet_dense_workspace_bytes(x.shape[-1], self.units), x.device)
         call('gunet_dense_forward_f32', ptr(x), rows, x.shape[-1], ptr(self.kernel), ptr(self.bias),
-             self.units, act, ptr(out), current_stream(x.device))
+             self.units, act, ptr(out), ptr(scratch), scratch.numel(), current_stream(x.device))
         return out
 
 

@@ -118,11 +118,30 @@ int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const 
                           const int32_t* perm, int64_t n_segments, int32_t batch, float scale,
                           float* out, gunet_stream_t stream);
 
+/* Arithmetic of every matrix product of the feature functions (Dense and the GN layer's node
+ * embeddings, edge MLP and node MLP).  Storage is float32 in all modes; the accumulator is float32.
+ *   GUNET_MATMUL_F32     v_mfma_f32_32x32x2_f32: exact float32 products (bitwise an fmaf chain).
+ *   GUNET_MATMUL_SPLIT3  each operand = sum of 3 bf16 pieces, 6 piece products on the bf16 matrix
+ *                        cores: float32-class accuracy (all dropped terms <= 2^-24 relative).
+ *   GUNET_MATMUL_SPLIT2  2 pieces, 3 products: about 2^-17 relative per product.
+ *   GUNET_MATMUL_BF16    operands rounded to bf16, 1 product: the bf16 tolerance class.
+ * The setting is process-wide and read at launch time.  No counterpart in the reference
+ * (TensorFlow float32 matmuls). */
+#define GUNET_MATMUL_F32 0
+#define GUNET_MATMUL_SPLIT3 1
+#define GUNET_MATMUL_SPLIT2 2
+#define GUNET_MATMUL_BF16 3
+int gunet_set_matmul_mode(int mode);
+int gunet_get_matmul_mode(void);
+
 /* tf.keras.layers.Dense (models/graph_unet.py:37,58,66,82): out = act(x @ kernel + bias).
- * x [rows, k]; kernel [k, n_out]; bias [n_out] or NULL; out [rows, n_out]. */
+ * x [rows, k]; kernel [k, n_out]; bias [n_out] or NULL; out [rows, n_out].
+ * workspace: gunet_dense_workspace_bytes(k, n_out) bytes, 16-byte aligned; may be NULL in
+ * GUNET_MATMUL_F32 mode. */
+size_t gunet_dense_workspace_bytes(int32_t k, int32_t n_out);
 int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float* kernel,
                             const float* bias, int32_t n_out, int32_t activation, float* out,
-                            gunet_stream_t stream);
+                            void* workspace, size_t workspace_bytes, gunet_stream_t stream);
 
 /* One quadrant graph: 4 reference-ordered edge lists and their receiver CSRs. */
 typedef struct gunet_quadgraph {

@@ -275,3 +275,34 @@ def test_graph_upsampling_layer(amd, oracle):
     bx, bg = up(to_dev(x).unsqueeze(0).repeat(3, 1, 1), cb, fb)
     for b in range(3):
         assert torch.equal(bx[b], got_x) and torch.equal(bg['global'][b], got_g['global'][0])
+
+
+@pytest.mark.parametrize('mode,tol', [('split3', 1e-5), ('bf16', 2e-2)])
+def test_matmul_modes(amd, oracle, mode, tol):
+    """The bf16-matrix-core modes: 'split3' (three bf16 pieces per operand, six products) holds the
+    float32 gate of 1e-5, 'bf16' (one product) the bf16 gate of 2e-2; storage stays float32."""
+    x, graph, _ = make_case(oracle, 40, 52, 0.45)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    assert amd.get_matmul_mode() == 'f32'
+    amd.set_matmul_mode(mode)
+    try:
+        assert amd.get_matmul_mode() == mode
+        model = _unet(amd, oracle, W)
+        got_y, got_g = model(to_dev(x), graph_to_dev(graph))
+        got_y, got_glob = got_y.cpu().numpy(), got_g['global'].cpu().numpy()
+        rng = np.random.Generator(np.random.PCG64(4))
+        xd = rng.standard_normal((3000, 104)).astype(np.float32)
+        wd = (rng.standard_normal((104, 96)) * 0.1).astype(np.float32)
+        layer = amd.hybrid_gnn.Dense(96, use_bias=False)
+        layer.load_weights({'d/kernel': wd}, 'd', 'cuda')
+        got_d = layer(to_dev(xd)).cpu().numpy()
+    finally:
+        amd.set_matmul_mode('f32')
+    assert rel_err(got_y, want_y) <= tol
+    assert rel_err(got_glob, want_g['global']) <= tol
+    assert rel_err(got_d, xd.astype(np.float64) @ wd.astype(np.float64)) <= tol
+    if mode == 'bf16':
+        assert rel_err(got_y, want_y) > 1e-5           # the mode really is on
+    with pytest.raises(amd.GunetError):
+        amd._lib.call('gunet_set_matmul_mode', 17)

@@ -26,6 +26,8 @@ def time_ms(fn, iters=10, warm=3):
 
 def gemm():
     dev = torch.device('cuda')
+    if os.environ.get('GUNET_MODE'):
+        gunet_amd.set_matmul_mode(os.environ['GUNET_MODE'])
     rows = 96493 * 8
     for k, n in [(128, 128), (256, 128), (384, 128), (104, 128), (128, 96)]:
         x = torch.rand((rows, k), device=dev)
@@ -33,11 +35,15 @@ def gemm():
         b = torch.rand((n,), device=dev)
         out = torch.empty((rows, n), device=dev)
         st = current_stream(dev)
-        fn = lambda: call('gunet_dense_forward_f32', ptr(x), rows, k, ptr(w), ptr(b), n, 1, ptr(out), st)
+        wsb = torch.empty(gunet_amd._lib.lib.gunet_dense_workspace_bytes(k, n), dtype=torch.uint8, device=dev)
+        fn = lambda: call('gunet_dense_forward_f32', ptr(x), rows, k, ptr(w), ptr(b), n, 1, ptr(out), ptr(wsb), wsb.numel(), st)
         ms = time_ms(fn)
         ref = torch.relu(x[:4096].double() @ w.double() + b.double())
+        fn()
         err = float((out[:4096].double() - ref).abs().max() / ref.abs().max())
         print(f'gemm rows={rows} k={k} n={n}: {ms:.3f} ms  {2.0 * rows * k * n / ms / 1e9:.1f} TFLOP/s  err {err:.1e}', flush=True)
+
+
 
 
 if __name__ == '__main__':
