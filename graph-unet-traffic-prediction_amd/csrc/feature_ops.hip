@@ -604,10 +604,12 @@ struct LayerPtrs {
   float gsn, gse;
 };
 
-constexpr int kSmallThreads = 1024;   // the two per-sample kernels: 8 k-groups x 128 columns
-constexpr int kGroups = kSmallThreads / kUnits;
+constexpr int kSmallThreads = 1024;   // the two per-sample kernels
+constexpr int kGroups = kSmallThreads / kUnits;   // 8 k-groups x 128 columns
+constexpr int kQuadCols = kUnits / 4;              // 32 column quads (float4) ...
+constexpr int kSubsets = kSmallThreads / kQuadCols;   // ... x 32 row subsets
 
-// Sum of `n` per-group partials for column `col`, in group order.
+// Sum of the 8 per-group partials for column `col`, in group order.
 __device__ inline float combine_groups(const float* part, int col) {
   float s = part[col];
 #pragma unroll
@@ -615,68 +617,147 @@ __device__ inline float combine_groups(const float* part, int col) {
   return s;
 }
 
+// y[col quad] += sum over rows r = sub, sub + 32, ... < n_rows of v[r] * W[r][4*cq .. 4*cq+3]
+// (W row-major with 128 columns); partial sums go to part4[sub][cq]; the caller adds the 32
+// subsets in order.  Four rows are in flight per thread.
+__device__ inline float4 matvec_partial(const float* v, const float* w, int n_rows, int sub, int cq) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* w4 = reinterpret_cast<const float4*>(w) + cq;
+  int r = sub;
+  for (; r + 3 * kSubsets < n_rows; r += 4 * kSubsets) {
+    const float4 a0 = w4[static_cast<int64_t>(r) * kQuadCols];
+    const float4 a1 = w4[static_cast<int64_t>(r + kSubsets) * kQuadCols];
+    const float4 a2 = w4[static_cast<int64_t>(r + 2 * kSubsets) * kQuadCols];
+    const float4 a3 = w4[static_cast<int64_t>(r + 3 * kSubsets) * kQuadCols];
+    const float v0 = v[r], v1 = v[r + kSubsets], v2 = v[r + 2 * kSubsets], v3 = v[r + 3 * kSubsets];
+    s.x = fmaf(v3, a3.x, fmaf(v2, a2.x, fmaf(v1, a1.x, fmaf(v0, a0.x, s.x))));
+    s.y = fmaf(v3, a3.y, fmaf(v2, a2.y, fmaf(v1, a1.y, fmaf(v0, a0.y, s.y))));
+    s.z = fmaf(v3, a3.z, fmaf(v2, a2.z, fmaf(v1, a1.z, fmaf(v0, a0.z, s.z))));
+    s.w = fmaf(v3, a3.w, fmaf(v2, a2.w, fmaf(v1, a1.w, fmaf(v0, a0.w, s.w))));
+  }
+  for (; r < n_rows; r += kSubsets) {
+    const float4 a0 = w4[static_cast<int64_t>(r) * kQuadCols];
+    const float v0 = v[r];
+    s.x = fmaf(v0, a0.x, s.x);
+    s.y = fmaf(v0, a0.y, s.y);
+    s.z = fmaf(v0, a0.z, s.z);
+    s.w = fmaf(v0, a0.w, s.w);
+  }
+  return s;
+}
+
+// Adds the 32 subset partials of column `col` in subset order.
+__device__ inline float combine_subsets(const float* part4, int col) {
+  float s = part4[col];
+#pragma unroll 8
+  for (int g = 1; g < kSubsets; ++g) s += part4[g * kUnits + col];
+  return s;
+}
+
 // Per sample: the chained global transforms (hybrid_gnn.py:98-99), folded into the bias each
 // direction's edge MLP sees; the node MLP's global columns folded into its bias (:122-125);
-// and the four node-embedding biases laid side by side.  Every dot product is split over 8
-// thread groups by k (k = group, group + 8, ...) and the 8 partials are added in group order.
+// and the four node-embedding biases laid side by side.  Everything that does not depend on the
+// chain (the node-MLP bias, the constant receiver term of the upsampling form, and the weights the
+// later chain steps need) is fetched first, so the chain itself only waits on LDS.
 __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
                                                                   const float* __restrict__ global_in,
                                                                   int relu, int fold_receiver,
                                                                   float* __restrict__ nbias,
                                                                   float* __restrict__ ebias,
                                                                   float* __restrict__ gbias) {
-  extern __shared__ float sh[];
-  float* gl = sh;                      // [g]
-  float* gq = gl + p.g;                // [4][32]
-  float* part = gq + 4 * kU;           // [8][128]
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* part4 = sh;                          // [32][128]
+  float* gl = part4 + kSubsets * kUnits;      // [g]
+  float* gq = gl + p.g;                       // [4][32]
   const int tid = threadIdx.x;
   const int grp = tid >> 7, col = tid & 127;
+  const int sub = tid >> 5, cq = tid & 31;
   const int64_t b = blockIdx.x;
   for (int k = tid; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
+
+  // chain weights of steps 1..3 for thread (grp, col < 32): rows grp, grp+8, grp+16, grp+24
+  float wq[3][4];
+  if (col < kU) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wq[q - 1][i] = p.glob_w[q][(grp + kGroups * i) * kU + col];
+  }
+  // edge-bias weights (rows of the global block of the edge kernel) and the constant terms
+  const int eq = col >> 5, ej = col & 31;
+  float we[4];   // thread (grp, col): rows grp, grp+8, grp+16, grp+24 of direction eq
+  {
+    const float* w = p.edge_w[eq] + static_cast<int64_t>(p.f_e + 2 * kU) * kU;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) we[i] = w[(grp + kGroups * i) * kU + ej];
+  }
+  float e_const = 0.0f;
+  if (tid < kUnits) {
+    if (p.edge_b[eq]) e_const = p.edge_b[eq][ej];
+    if (fold_receiver) {
+      // every receiver is a zero input row: its embedding is act(bias), a constant of the layer
+      const float* wr = p.edge_w[eq] + static_cast<int64_t>(p.f_e + kU) * kU;
+      float r = 0.0f;
+      for (int k = 0; k < kU; ++k)
+        r = fmaf(activate(p.node_emb_b[eq] ? p.node_emb_b[eq][k] : 0.0f, relu), wr[k * kU + ej], r);
+      e_const += r;
+    }
+    if (b == 0) nbias[tid] = p.node_emb_b[eq] ? p.node_emb_b[eq][ej] : 0.0f;
+  }
   __syncthreads();
-  for (int q = 0; q < 4; ++q) {
-    const float* src = q == 0 ? gl : gq + (q - 1) * kU;
-    const int kk = q == 0 ? p.g : kU;
+
+  // node-MLP bias: global . W[c_in + 128 .., :]
+  {
+    const float4 s = matvec_partial(gl, p.node_w + static_cast<int64_t>(p.c_in + kUnits) * kUnits, p.g, sub, cq);
+    *reinterpret_cast<float4*>(&part4[sub * kUnits + 4 * cq]) = s;
+  }
+  __syncthreads();
+  if (tid < kUnits) {
+    float s = combine_subsets(part4, tid);
+    if (p.node_b) s += p.node_b[tid];
+    gbias[b * kUnits + tid] = s;
+  }
+  __syncthreads();
+
+  // chain step 0: [g] -> 32
+  if (col < kU) {
+    float s = 0.0f;
+    for (int k = grp; k < p.g; k += kGroups) s = fmaf(gl[k], p.glob_w[0][k * kU + col], s);
+    part4[grp * kUnits + col] = s;
+  }
+  __syncthreads();
+  if (tid < kU) {
+    float s = combine_groups(part4, tid);
+    if (p.glob_b[0]) s += p.glob_b[0][tid];
+    gq[tid] = activate(s, relu);
+  }
+  __syncthreads();
+  // chain steps 1..3: 32 -> 32 with the preloaded weights
+  for (int q = 1; q < 4; ++q) {
     if (col < kU) {
+      const float* src = gq + (q - 1) * kU;
       float s = 0.0f;
-      for (int k = grp; k < kk; k += kGroups) s = fmaf(src[k], p.glob_w[q][k * kU + col], s);
-      part[grp * kUnits + col] = s;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s = fmaf(src[grp + kGroups * i], wq[q - 1][i], s);
+      part4[grp * kUnits + col] = s;
     }
     __syncthreads();
     if (tid < kU) {
-      float s = combine_groups(part, tid);
+      float s = combine_groups(part4, tid);
       if (p.glob_b[q]) s += p.glob_b[q][tid];
       gq[q * kU + tid] = activate(s, relu);
     }
     __syncthreads();
   }
+  // edge bias of direction eq: chained global of that direction . W_global + constants
   {
-    const float* w = p.node_w + static_cast<int64_t>(p.c_in + kUnits) * kUnits;
     float s = 0.0f;
-    for (int k = grp; k < p.g; k += kGroups) s = fmaf(gl[k], w[static_cast<int64_t>(k) * kUnits + col], s);
-    part[grp * kUnits + col] = s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s = fmaf(gq[eq * kU + grp + kGroups * i], we[i], s);
+    part4[grp * kUnits + col] = s;
   }
   __syncthreads();
-  if (tid < kUnits) {
-    float s = combine_groups(part, tid);
-    if (p.node_b) s += p.node_b[tid];
-    gbias[b * kUnits + tid] = s;
-    const int q = tid >> 5, j = tid & 31;
-    const float* w = p.edge_w[q] + static_cast<int64_t>(p.f_e + 2 * kU) * kU;
-    float e = 0.0f;
-    for (int k = 0; k < kU; ++k) e = fmaf(gq[q * kU + k], w[k * kU + j], e);
-    if (p.edge_b[q]) e += p.edge_b[q][j];
-    if (fold_receiver) {
-      // every receiver is a zero input row: its embedding is act(bias), a constant of the layer
-      const float* wr = p.edge_w[q] + static_cast<int64_t>(p.f_e + kU) * kU;
-      float r = 0.0f;
-      for (int k = 0; k < kU; ++k)
-        r = fmaf(activate(p.node_emb_b[q] ? p.node_emb_b[q][k] : 0.0f, relu), wr[k * kU + j], r);
-      e += r;
-    }
-    ebias[b * kUnits + tid] = e;
-    if (b == 0) nbias[tid] = p.node_emb_b[q] ? p.node_emb_b[q][j] : 0.0f;
-  }
+  if (tid < kUnits) ebias[b * kUnits + tid] = combine_groups(part4, tid) + e_const;
 }
 
 struct EdgeArgs {
@@ -836,37 +917,62 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
   *reinterpret_cast<float4*>(a.agg + (b * a.n_nodes + v) * kUnits + kU * q + 4 * c4) = acc;
 }
 
-// Per sample: finish the node / edge column sums (fp64 accumulation over the per-block
-// partials, block i handled by thread group i mod 8, groups combined in order), scale them and
-// apply the global transform (hybrid_gnn.py:130-135).
+// Per sample: finish the node / edge column sums (fp64 accumulation over the per-tile partials:
+// 32 thread subsets take tiles sub, sub + 32, ... with float4 loads, the subsets are then added in
+// order), scale them and apply the global transform (hybrid_gnn.py:130-135).
 __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
                                                                  const float* __restrict__ global_in,
                                                                  const float* __restrict__ npart, int n_nblk,
                                                                  const float* __restrict__ epart, int n_eblk,
                                                                  int relu, float* __restrict__ global_out) {
   extern __shared__ __attribute__((aligned(16))) float gsh[];
-  double* dpart = reinterpret_cast<double*>(gsh);                    // [8][128]
-  float* part = reinterpret_cast<float*>(dpart + kGroups * kUnits);  // [8][128]
-  float* gin = part + kGroups * kUnits;                              // [g + 128 + 32]
+  double* dpart = reinterpret_cast<double*>(gsh);                      // [32][128]
+  float* part4 = reinterpret_cast<float*>(dpart + kSubsets * kUnits);  // [32][128]
+  float* gin = part4 + kSubsets * kUnits;                              // [g + 128 + 32]
   const int tid = threadIdx.x;
-  const int grp = tid >> 7, col = tid & 127;
+  const int sub = tid >> 5, cq = tid & 31;
   const int64_t b = blockIdx.x;
   for (int k = tid; k < p.g; k += blockDim.x) gin[k] = global_in[b * p.g + k];
   {
-    double s = 0.0;
-    const float* src = npart + b * n_nblk * static_cast<int64_t>(kUnits) + col;
-    for (int i = grp; i < n_nblk; i += kGroups) s += static_cast<double>(src[static_cast<int64_t>(i) * kUnits]);
-    dpart[grp * kUnits + col] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const float4* src = reinterpret_cast<const float4*>(npart + b * n_nblk * static_cast<int64_t>(kUnits)) + cq;
+    int i = sub;
+    for (; i + kSubsets < n_nblk; i += 2 * kSubsets) {
+      const float4 a = src[static_cast<int64_t>(i) * kQuadCols];
+      const float4 c = src[static_cast<int64_t>(i + kSubsets) * kQuadCols];
+      s0 += static_cast<double>(a.x);
+      s1 += static_cast<double>(a.y);
+      s2 += static_cast<double>(a.z);
+      s3 += static_cast<double>(a.w);
+      s0 += static_cast<double>(c.x);
+      s1 += static_cast<double>(c.y);
+      s2 += static_cast<double>(c.z);
+      s3 += static_cast<double>(c.w);
+    }
+    for (; i < n_nblk; i += kSubsets) {
+      const float4 a = src[static_cast<int64_t>(i) * kQuadCols];
+      s0 += static_cast<double>(a.x);
+      s1 += static_cast<double>(a.y);
+      s2 += static_cast<double>(a.z);
+      s3 += static_cast<double>(a.w);
+    }
+    double* d = dpart + sub * kUnits + 4 * cq;
+    d[0] = s0;
+    d[1] = s1;
+    d[2] = s2;
+    d[3] = s3;
   }
   __syncthreads();
   if (tid < kUnits) {
     double s = dpart[tid];
-    for (int g = 1; g < kGroups; ++g) s += dpart[g * kUnits + tid];
+    for (int g = 1; g < kSubsets; ++g) s += dpart[g * kUnits + tid];
     const float denom = p.gsn * 300.0f * 300.0f;
     gin[p.g + tid] = (static_cast<float>(s) * 1.0f) / denom;
   }
   __syncthreads();
   {
+    // message sums: [4 directions][n_eblk][32]; thread (grp, col) with col = 32*q + c
+    const int grp = tid >> 7, col = tid & 127;
     const int q = col >> 5, c = col & 31;
     double s = 0.0;
     const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(kU) + c;
@@ -887,12 +993,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
   __syncthreads();
   const int kin = p.g + kUnits + kU;
   if (p.globt_w != nullptr) {
-    float s = 0.0f;
-    for (int k = grp; k < kin; k += kGroups) s = fmaf(gin[k], p.globt_w[static_cast<int64_t>(k) * kUnits + col], s);
-    part[grp * kUnits + col] = s;
+    const float4 s = matvec_partial(gin, p.globt_w, kin, sub, cq);
+    *reinterpret_cast<float4*>(&part4[sub * kUnits + 4 * cq]) = s;
     __syncthreads();
     if (tid < kUnits) {
-      float t = combine_groups(part, tid);
+      float t = combine_subsets(part4, tid);
       if (p.globt_b) t += p.globt_b[tid];
       global_out[b * kUnits + tid] = activate(t, relu);
     }
@@ -955,7 +1060,7 @@ int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_g
   }
   GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0 && w->c_in <= kMaxCin,
                 "%s: c_in = %d must be a positive multiple of 4, at most %d", fn, w->c_in, kMaxCin);
-  GUNET_REQUIRE(w->g > 0 && w->g <= 4096, "%s: global width %d outside 1..4096", fn, w->g);
+  GUNET_REQUIRE(w->g > 0 && w->g <= 2048, "%s: global width %d outside 1..2048", fn, w->g);
   if (w->f_e < 0 || w->f_e > 64) {
     set_error("%s: edge feature width %d outside 0..64 is not implemented", fn, w->f_e);
     return GUNET_ERR_UNSUPPORTED;
@@ -1002,7 +1107,7 @@ LayerPtrs layer_ptrs(const gunet_gn_weights* w) {
 int launch_prologue(const LayerPtrs& p, const float* global_in, int relu, int fold_receiver, int32_t batch,
                     const LayerWorkspace& ws, hipStream_t stream) {
   ProfScope prof(kProfPrologue, stream);
-  k_layer_prologue<<<batch, kSmallThreads, sizeof(float) * (p.g + 4 * kU + kGroups * kUnits), stream>>>(
+  k_layer_prologue<<<batch, kSmallThreads, sizeof(float) * (kSubsets * kUnits + p.g + 4 * kU), stream>>>(
       p, global_in, relu, fold_receiver, ws.nbias, ws.ebias, ws.gbias);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
@@ -1012,7 +1117,7 @@ int launch_global_update(const LayerPtrs& p, const float* global_in, int n_nblk,
                          const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
   ProfScope prof(kProfGlobalUpdate, stream);
   k_global_update<<<batch, kSmallThreads,
-                    sizeof(double) * kGroups * kUnits + sizeof(float) * (kGroups * kUnits + p.g + kUnits + kU),
+                    sizeof(double) * kSubsets * kUnits + sizeof(float) * (kSubsets * kUnits + p.g + kUnits + kU),
                     stream>>>(p, global_in, ws.npart, n_nblk, ws.epart, ws.n_eblk, relu, global_out);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
