@@ -6,6 +6,7 @@
 //     receiver-CSR aggregation, node MLP GEMM and the small global-feature updates.
 // All reductions are atomic-free and run in a fixed order, so outputs are bitwise reproducible.
 #include <cfloat>
+#include <type_traits>
 
 #include "common.h"
 
@@ -585,7 +586,7 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
 
 constexpr int kU = 32;           // per-direction width (units / 4)
 constexpr int kUnits = 128;
-constexpr int kEdgeGroups = 4;   // 32-edge groups per wave
+constexpr int kEdgeGroups = 8;   // 32-edge groups per wave
 constexpr int kEdgesPerBlock = 4 * 32 * kEdgeGroups;
 constexpr int kMaxCin = 1024;                       // widest layer input the workspace is sized for
 constexpr int kMaxKTiles = kMaxCin / kBK + 2 + kUnits / kBK;
@@ -776,13 +777,56 @@ struct EdgeArgs {
   float out_scale;          // stored message = out_scale * message (the column sums stay unscaled)
 };
 
-// Edge MLP for 32 edges per wave step: the A operand row of edge e is
+// Edge MLP, 32 edges per wave step: the A operand row of edge e is
 // [edge features | embedding of the sender | embedding of the receiver], gathered straight into
-// registers as float4 pieces (half-wave h takes floats 8c+4h..8c+4h+3 of every 8-float chunk);
-// the matching weight rows stay in registers for the whole workgroup.
+// MFMA registers as float4 pieces (half-wave h takes floats 8c+4h..8c+4h+3 of every 8-float
+// chunk).  The weight rows (zero-padded to whole chunks) sit in LDS for the workgroup.  Each wave
+// walks kEdgeGroups groups; the indices of group g+2 and the rows of group g+1 are requested
+// before the MFMAs of group g, and the stores of group g are issued after those requests, so
+// a wave always has gathers in flight behind its matrix work.
+template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
+struct EdgeRows {
+  static constexpr int CH = FE_CHUNKS + (SENDER_ONLY ? 4 : 8);
+  float4 v[CH];
+};
+
+template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
+__device__ inline void gather_edge_rows(const float* __restrict__ xq, const float* __restrict__ ef, int f_e,
+                                        int64_t e, int2 sr, int lh,
+                                        EdgeRows<FE_CHUNKS, FE_VEC, SENDER_ONLY>& rows) {
+  if (FE_CHUNKS > 0) {
+    if (FE_VEC) {
+      const float4* pf = reinterpret_cast<const float4*>(ef + e * f_e) + lh;
+#pragma unroll
+      for (int c = 0; c < FE_CHUNKS; ++c) rows.v[c] = pf[2 * c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < FE_CHUNKS; ++c) {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 8 * c + 4 * lh + j;
+          t[j] = (ef != nullptr && k < f_e) ? ef[e * f_e + k] : 0.0f;
+        }
+        rows.v[c] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+  }
+  const float4* ps = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.x) * kUnits) + lh;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rows.v[FE_CHUNKS + c] = ps[2 * c];
+  if (!SENDER_ONLY) {
+    const float4* pr = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.y) * kUnits) + lh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rows.v[FE_CHUNKS + 4 + c] = pr[2 * c];
+  }
+}
+
 template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
 __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
-  constexpr int CH = FE_CHUNKS + (SENDER_ONLY ? 4 : 8);
+  using Rows = EdgeRows<FE_CHUNKS, FE_VEC, SENDER_ONLY>;
+  constexpr int CH = Rows::CH;
+  __shared__ float Ws[CH * 8 * kU];
   __shared__ float red[4 * kU];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -793,78 +837,81 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
   const int64_t block_base = static_cast<int64_t>(blockIdx.x) * kEdgesPerBlock;
   float colsum = 0.0f;
 
-  if (block_base < n_edges) {
+  if (block_base < n_edges) {   // uniform over the workgroup
     const float* w = a.edge_w[q];
-    float wreg[CH * 4];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int row;
-        if (c < FE_CHUNKS) {
-          row = 8 * c + 4 * lh + j;
-          wreg[4 * c + j] = row < a.f_e ? w[row * kU + li] : 0.0f;
-        } else {
-          row = a.f_e + 8 * (c - FE_CHUNKS) + 4 * lh + j;
-          wreg[4 * c + j] = w[row * kU + li];
-        }
-      }
+    for (int i = tid; i < CH * 8 * kU; i += kThreads) {
+      const int row = i >> 5, col = i & 31;
+      float v;
+      if (row < 8 * FE_CHUNKS)
+        v = row < a.f_e ? w[row * kU + col] : 0.0f;
+      else
+        v = w[(a.f_e + row - 8 * FE_CHUNKS) * kU + col];
+      Ws[i] = v;
     }
+    __syncthreads();
     const float bias = a.ebias[(b * 4 + q) * kU + li];
     const int2* ei = reinterpret_cast<const int2*>(a.edge_index[q]);
     const float* xq = a.xq + b * a.n_nodes * static_cast<int64_t>(kUnits) + kU * q;
     const float* ef = a.efeat[q] ? a.efeat[q] + b * n_edges * static_cast<int64_t>(a.f_e) : nullptr;
     float* out = a.out[q] + b * n_edges * static_cast<int64_t>(kU);
+    const int64_t wave_base = block_base + static_cast<int64_t>(wave) * kEdgeGroups * 32;
+    auto edge_of = [&](int grp) {
+      const int64_t e = wave_base + grp * 32 + li;
+      return e < n_edges ? e : static_cast<int64_t>(n_edges) - 1;   // clamped lanes are masked at the store
+    };
 
-    for (int grp = 0; grp < kEdgeGroups; ++grp) {
-      const int64_t e0 = block_base + (wave * kEdgeGroups + grp) * 32;
-      if (e0 >= n_edges) break;
-      const int64_t e = e0 + li < n_edges ? e0 + li : n_edges - 1;
-      const int2 sr = ei[e];
-      float4 av[CH];
-      if (FE_CHUNKS > 0) {
-        if (FE_VEC) {
-          const float4* pf = reinterpret_cast<const float4*>(ef + e * a.f_e) + lh;
-#pragma unroll
-          for (int c = 0; c < FE_CHUNKS; ++c) av[c] = pf[2 * c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < FE_CHUNKS; ++c) {
-            float t[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int k = 8 * c + 4 * lh + j;
-              t[j] = (ef != nullptr && k < a.f_e) ? ef[e * a.f_e + k] : 0.0f;
-            }
-            av[c] = make_float4(t[0], t[1], t[2], t[3]);
-          }
-        }
+    // One group: request the rows of group grp+1 into `nxt` (its indices were fetched a step
+    // earlier) and the indices of group grp+2, then multiply the rows of group grp held in `cur`.
+    // The two row buffers swap roles every step (no register copies, which would have to wait
+    // for the loads they copy).  FULL = every edge of the wave's groups exists: no clamps, no
+    // masks and no branches, so the whole sweep is one basic block and the requests stay where
+    // they are written, ahead of the matrix work of the previous group.
+    auto step = [&](auto full_tag, int grp, Rows& cur, Rows& nxt, int2& sr_nxt, int2& sr_nxt2) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      const int64_t e0 = wave_base + grp * 32;
+      if (grp + 1 < kEdgeGroups && (FULL || e0 + 32 < n_edges)) {
+        if (grp + 2 < kEdgeGroups) sr_nxt2 = ei[FULL ? e0 + 64 + li : edge_of(grp + 2)];
+        gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY>(xq, ef, a.f_e, FULL ? e0 + 32 + li : edge_of(grp + 1),
+                                                         sr_nxt, lh, nxt);
       }
-      const float4* ps = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.x) * kUnits) + lh;
-      const float4* pr = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.y) * kUnits) + lh;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        av[FE_CHUNKS + c] = ps[2 * c];
-        if (!SENDER_ONLY) av[FE_CHUNKS + 4 + c] = pr[2 * c];
-      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests above the matrix work
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, wreg[4 * c + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, wreg[4 * c + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, wreg[4 * c + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, wreg[4 * c + 3], acc, 0, 0, 0);
+        const float a4[4] = {cur.v[c].x, cur.v[c].y, cur.v[c].z, cur.v[c].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], Ws[(8 * c + 4 * lh + j) * kU + li], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = e0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float v = activate(acc[r] + bias, a.relu);
-        if (row < n_edges) {
+        if (FULL || row < n_edges) {
           out[row * kU + li] = v * a.out_scale;
           colsum += v;
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Rows r0, r1;
+    int2 sr_a, sr_b;
+    if (wave_base + kEdgeGroups * 32 <= n_edges) {
+      sr_a = ei[wave_base + 32 + li];
+      gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY>(xq, ef, a.f_e, wave_base + li, ei[wave_base + li], lh, r0);
+#pragma unroll
+      for (int grp = 0; grp < kEdgeGroups; grp += 2) {
+        step(std::true_type{}, grp, r0, r1, sr_a, sr_b);
+        step(std::true_type{}, grp + 1, r1, r0, sr_b, sr_a);
+      }
+    } else if (wave_base < n_edges) {
+      sr_a = ei[edge_of(1)];
+      gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY>(xq, ef, a.f_e, edge_of(0), ei[edge_of(0)], lh, r0);
+      for (int grp = 0; grp < kEdgeGroups && wave_base + grp * 32 < n_edges; grp += 2) {
+        step(std::false_type{}, grp, r0, r1, sr_a, sr_b);
+        if (wave_base + (grp + 1) * 32 < n_edges) step(std::false_type{}, grp + 1, r1, r0, sr_b, sr_a);
       }
     }
   }
