@@ -139,7 +139,8 @@ struct GemmArgs {
   int row_map_sub;
   float* colsum;              // per-tile column sums of the activated output, or null:
   int colsum_tiles;           //   [B][colsum_tiles][32*NT], this launch fills tiles
-  int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + gridDim.x - 1
+  int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + gridDim.x - 1; row stride colsum_ld
+  int colsum_ld;              //   floats (0 = 32*NT), this launch's columns start at out_col0
   int relu;
 };
 
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
     __syncthreads();
     if (tid < BN) {
       const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * BN + tid] = s;
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
 }
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
     __syncthreads();
     if (tid < BN) {
       const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * BN + tid] = s;
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
 }
@@ -563,6 +564,13 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
   if (g.out_rows == 0) g.out_rows = g.n_rows;
   dim3 grid(static_cast<unsigned>(ceil_div(g.n_rows, kBM)), static_cast<unsigned>(batch));
   if (g.colsum != nullptr && g.colsum_tiles == 0) g.colsum_tiles = static_cast<int>(grid.x);
+  if (g.colsum_ld == 0) {
+    g.colsum_ld = 32 * nt;
+    if (g.colsum != nullptr && g.out_col0 != 0) {
+      set_error("launch_gemm: column sums of a column block need colsum_ld");
+      return GUNET_ERR_INVALID;
+    }
+  }
   ProfScope prof(kProfGemm, stream);
   const int pieces = mode_pieces(g_matmul_mode);
   if (pieces > 0 && wpack != nullptr) {
@@ -583,13 +591,14 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
 }
 
 // ---------------------------------------------------------------- GeoQuadrantGCN pieces
+//
+// Kernels of one GN layer, templated on UT = units / 128: U = 128*UT output columns per node,
+// u = 32*UT per direction.  UT = 1 is the shipped checkpoint's width, UT = 2 the 256-wide variant.
 
-constexpr int kU = 32;           // per-direction width (units / 4)
-constexpr int kUnits = 128;
 constexpr int kEdgeGroups = 8;   // 32-edge groups per wave
 constexpr int kEdgesPerBlock = 4 * 32 * kEdgeGroups;
-constexpr int kMaxCin = 1024;                       // widest layer input the workspace is sized for
-constexpr int kMaxKTiles = kMaxCin / kBK + 2 + kUnits / kBK;
+constexpr int kMaxCin = 1024;    // widest layer input the workspace is sized for
+constexpr int kMaxUT = 2;
 
 struct LayerPtrs {
   const float* node_emb_b[4];
@@ -606,38 +615,29 @@ struct LayerPtrs {
 };
 
 constexpr int kSmallThreads = 1024;   // the two per-sample kernels
-constexpr int kGroups = kSmallThreads / kUnits;   // 8 k-groups x 128 columns
-constexpr int kQuadCols = kUnits / 4;              // 32 column quads (float4) ...
-constexpr int kSubsets = kSmallThreads / kQuadCols;   // ... x 32 row subsets
 
-// Sum of the 8 per-group partials for column `col`, in group order.
-__device__ inline float combine_groups(const float* part, int col) {
-  float s = part[col];
-#pragma unroll
-  for (int g = 1; g < kGroups; ++g) s += part[g * kUnits + col];
-  return s;
-}
-
-// y[col quad] += sum over rows r = sub, sub + 32, ... < n_rows of v[r] * W[r][4*cq .. 4*cq+3]
-// (W row-major with 128 columns); partial sums go to part4[sub][cq]; the caller adds the 32
-// subsets in order.  Four rows are in flight per thread.
+// y[4*cq .. 4*cq+3] = sum over rows r = sub, sub + S, ... < n_rows of v[r] * W[r][4*cq ..] for W
+// row-major with U columns, S = 1024 / (U/4) row subsets; the caller adds the S subsets in
+// order.  Four rows are in flight per thread.
+template <int U>
 __device__ inline float4 matvec_partial(const float* v, const float* w, int n_rows, int sub, int cq) {
+  constexpr int QC = U / 4, S = kSmallThreads / QC;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* w4 = reinterpret_cast<const float4*>(w) + cq;
   int r = sub;
-  for (; r + 3 * kSubsets < n_rows; r += 4 * kSubsets) {
-    const float4 a0 = w4[static_cast<int64_t>(r) * kQuadCols];
-    const float4 a1 = w4[static_cast<int64_t>(r + kSubsets) * kQuadCols];
-    const float4 a2 = w4[static_cast<int64_t>(r + 2 * kSubsets) * kQuadCols];
-    const float4 a3 = w4[static_cast<int64_t>(r + 3 * kSubsets) * kQuadCols];
-    const float v0 = v[r], v1 = v[r + kSubsets], v2 = v[r + 2 * kSubsets], v3 = v[r + 3 * kSubsets];
+  for (; r + 3 * S < n_rows; r += 4 * S) {
+    const float4 a0 = w4[static_cast<int64_t>(r) * QC];
+    const float4 a1 = w4[static_cast<int64_t>(r + S) * QC];
+    const float4 a2 = w4[static_cast<int64_t>(r + 2 * S) * QC];
+    const float4 a3 = w4[static_cast<int64_t>(r + 3 * S) * QC];
+    const float v0 = v[r], v1 = v[r + S], v2 = v[r + 2 * S], v3 = v[r + 3 * S];
     s.x = fmaf(v3, a3.x, fmaf(v2, a2.x, fmaf(v1, a1.x, fmaf(v0, a0.x, s.x))));
     s.y = fmaf(v3, a3.y, fmaf(v2, a2.y, fmaf(v1, a1.y, fmaf(v0, a0.y, s.y))));
     s.z = fmaf(v3, a3.z, fmaf(v2, a2.z, fmaf(v1, a1.z, fmaf(v0, a0.z, s.z))));
     s.w = fmaf(v3, a3.w, fmaf(v2, a2.w, fmaf(v1, a1.w, fmaf(v0, a0.w, s.w))));
   }
-  for (; r < n_rows; r += kSubsets) {
-    const float4 a0 = w4[static_cast<int64_t>(r) * kQuadCols];
+  for (; r < n_rows; r += S) {
+    const float4 a0 = w4[static_cast<int64_t>(r) * QC];
     const float v0 = v[r];
     s.x = fmaf(v0, a0.x, s.x);
     s.y = fmaf(v0, a0.y, s.y);
@@ -647,11 +647,10 @@ __device__ inline float4 matvec_partial(const float* v, const float* w, int n_ro
   return s;
 }
 
-// Adds the 32 subset partials of column `col` in subset order.
-__device__ inline float combine_subsets(const float* part4, int col) {
-  float s = part4[col];
-#pragma unroll 8
-  for (int g = 1; g < kSubsets; ++g) s += part4[g * kUnits + col];
+// Adds `n` partials of column `col` (row stride `ld`) in order.
+__device__ inline float combine_rows(const float* part, int n, int ld, int col) {
+  float s = part[col];
+  for (int g = 1; g < n; ++g) s += part[g * ld + col];
   return s;
 }
 
@@ -660,118 +659,116 @@ __device__ inline float combine_subsets(const float* part4, int col) {
 // and the four node-embedding biases laid side by side.  Everything that does not depend on the
 // chain (the node-MLP bias, the constant receiver term of the upsampling form, and the weights the
 // later chain steps need) is fetched first, so the chain itself only waits on LDS.
+template <int UT>
 __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
                                                                   const float* __restrict__ global_in,
                                                                   int relu, int fold_receiver,
                                                                   float* __restrict__ nbias,
                                                                   float* __restrict__ ebias,
                                                                   float* __restrict__ gbias) {
+  constexpr int U = 128 * UT, u = 32 * UT;
+  constexpr int QC = U / 4, S = kSmallThreads / QC;     // matvec: column quads x row subsets
+  constexpr int CG = kSmallThreads / u, CR = u / CG;    // chain: CG row groups, CR rows each (u -> u steps)
+  constexpr int EG = kSmallThreads / U, ER = u / EG;    // edge bias: EG row groups, ER rows each
   extern __shared__ __attribute__((aligned(16))) float sh[];
-  float* part4 = sh;                          // [32][128]
-  float* gl = part4 + kSubsets * kUnits;      // [g]
-  float* gq = gl + p.g;                       // [4][32]
+  float* part = sh;                      // 4096 floats, reused by every reduction
+  float* gl = part + 4096;               // [g]
+  float* gq = gl + p.g;                  // [4][u]
   const int tid = threadIdx.x;
-  const int grp = tid >> 7, col = tid & 127;
-  const int sub = tid >> 5, cq = tid & 31;
   const int64_t b = blockIdx.x;
   for (int k = tid; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
 
-  // chain weights of steps 1..3 for thread (grp, col < 32): rows grp, grp+8, grp+16, grp+24
-  float wq[3][4];
-  if (col < kU) {
+  const int cgrp = tid / u, ccol = tid % u;
+  float wq[3][CR];
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+  for (int q = 1; q < 4; ++q)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wq[q - 1][i] = p.glob_w[q][(grp + kGroups * i) * kU + col];
-  }
-  // edge-bias weights (rows of the global block of the edge kernel) and the constant terms
-  const int eq = col >> 5, ej = col & 31;
-  float we[4];   // thread (grp, col): rows grp, grp+8, grp+16, grp+24 of direction eq
+    for (int i = 0; i < CR; ++i) wq[q - 1][i] = p.glob_w[q][(cgrp + CG * i) * u + ccol];
+  const int egrp = tid / U, ecol = tid % U;
+  const int eq = ecol / u, ej = ecol % u;
+  float we[ER];
   {
-    const float* w = p.edge_w[eq] + static_cast<int64_t>(p.f_e + 2 * kU) * kU;
+    const float* w = p.edge_w[eq] + static_cast<int64_t>(p.f_e + 2 * u) * u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) we[i] = w[(grp + kGroups * i) * kU + ej];
+    for (int i = 0; i < ER; ++i) we[i] = w[(egrp + EG * i) * u + ej];
   }
   float e_const = 0.0f;
-  if (tid < kUnits) {
+  if (tid < U) {
     if (p.edge_b[eq]) e_const = p.edge_b[eq][ej];
     if (fold_receiver) {
       // every receiver is a zero input row: its embedding is act(bias), a constant of the layer
-      const float* wr = p.edge_w[eq] + static_cast<int64_t>(p.f_e + kU) * kU;
+      const float* wr = p.edge_w[eq] + static_cast<int64_t>(p.f_e + u) * u;
       float r = 0.0f;
-      for (int k = 0; k < kU; ++k)
-        r = fmaf(activate(p.node_emb_b[eq] ? p.node_emb_b[eq][k] : 0.0f, relu), wr[k * kU + ej], r);
+      for (int k = 0; k < u; ++k)
+        r = fmaf(activate(p.node_emb_b[eq] ? p.node_emb_b[eq][k] : 0.0f, relu), wr[k * u + ej], r);
       e_const += r;
     }
     if (b == 0) nbias[tid] = p.node_emb_b[eq] ? p.node_emb_b[eq][ej] : 0.0f;
   }
   __syncthreads();
 
-  // node-MLP bias: global . W[c_in + 128 .., :]
-  {
-    const float4 s = matvec_partial(gl, p.node_w + static_cast<int64_t>(p.c_in + kUnits) * kUnits, p.g, sub, cq);
-    *reinterpret_cast<float4*>(&part4[sub * kUnits + 4 * cq]) = s;
+  {  // node-MLP bias: global . W[c_in + U .., :]
+    const int sub = tid / QC, cq = tid % QC;
+    const float4 s = matvec_partial<U>(gl, p.node_w + static_cast<int64_t>(p.c_in + U) * U, p.g, sub, cq);
+    *reinterpret_cast<float4*>(&part[sub * U + 4 * cq]) = s;
   }
   __syncthreads();
-  if (tid < kUnits) {
-    float s = combine_subsets(part4, tid);
+  if (tid < U) {
+    float s = combine_rows(part, S, U, tid);
     if (p.node_b) s += p.node_b[tid];
-    gbias[b * kUnits + tid] = s;
+    gbias[b * U + tid] = s;
   }
   __syncthreads();
 
-  // chain step 0: [g] -> 32
-  if (col < kU) {
+  {  // chain step 0: [g] -> u
     float s = 0.0f;
-    for (int k = grp; k < p.g; k += kGroups) s = fmaf(gl[k], p.glob_w[0][k * kU + col], s);
-    part4[grp * kUnits + col] = s;
+    for (int k = cgrp; k < p.g; k += CG) s = fmaf(gl[k], p.glob_w[0][k * u + ccol], s);
+    part[cgrp * u + ccol] = s;
   }
   __syncthreads();
-  if (tid < kU) {
-    float s = combine_groups(part4, tid);
+  if (tid < u) {
+    float s = combine_rows(part, CG, u, tid);
     if (p.glob_b[0]) s += p.glob_b[0][tid];
     gq[tid] = activate(s, relu);
   }
   __syncthreads();
-  // chain steps 1..3: 32 -> 32 with the preloaded weights
-  for (int q = 1; q < 4; ++q) {
-    if (col < kU) {
-      const float* src = gq + (q - 1) * kU;
+  for (int q = 1; q < 4; ++q) {   // chain steps 1..3: u -> u with the preloaded weights
+    {
+      const float* src = gq + (q - 1) * u;
       float s = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s = fmaf(src[grp + kGroups * i], wq[q - 1][i], s);
-      part4[grp * kUnits + col] = s;
+      for (int i = 0; i < CR; ++i) s = fmaf(src[cgrp + CG * i], wq[q - 1][i], s);
+      part[cgrp * u + ccol] = s;
     }
     __syncthreads();
-    if (tid < kU) {
-      float s = combine_groups(part4, tid);
+    if (tid < u) {
+      float s = combine_rows(part, CG, u, tid);
       if (p.glob_b[q]) s += p.glob_b[q][tid];
-      gq[q * kU + tid] = activate(s, relu);
+      gq[q * u + tid] = activate(s, relu);
     }
     __syncthreads();
   }
-  // edge bias of direction eq: chained global of that direction . W_global + constants
-  {
+  {  // edge bias of direction eq: chained global of that direction . W_global + constants
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s = fmaf(gq[eq * kU + grp + kGroups * i], we[i], s);
-    part4[grp * kUnits + col] = s;
+    for (int i = 0; i < ER; ++i) s = fmaf(gq[eq * u + egrp + EG * i], we[i], s);
+    part[egrp * U + ecol] = s;
   }
   __syncthreads();
-  if (tid < kUnits) ebias[b * kUnits + tid] = combine_groups(part4, tid) + e_const;
+  if (tid < U) ebias[b * U + tid] = combine_rows(part, EG, U, tid) + e_const;
 }
 
 struct EdgeArgs {
   const int32_t* edge_index[4];
   const float* efeat[4];    // [B, E_q, f_e] or null
-  const float* edge_w[4];   // [f_e + 96, 32]
-  float* out[4];            // [B, E_q, 32]
+  const float* edge_w[4];   // [f_e + 3u, u]
+  float* out[4];            // [B, E_q, u]
   int n_edges[4];
   int n_nodes;
   int f_e;
-  const float* xq;          // [B, N, 128] node embeddings, direction q in columns 32q..32q+31
-  const float* ebias;       // [B, 4, 32]
-  float* partial;           // [B, 4, gridDim.x, 32] column sums of the messages
+  const float* xq;          // [B, N, U] node embeddings, direction q in columns u*q .. u*q+u-1
+  const float* ebias;       // [B, 4, u]
+  float* partial;           // [B, 4, gridDim.x, u] column sums of the messages
   int relu;
   int sender_only;          // receivers contribute through the bias (graph upsampling)
   float out_scale;          // stored message = out_scale * message (the column sums stay unscaled)
@@ -781,19 +778,19 @@ struct EdgeArgs {
 // [edge features | embedding of the sender | embedding of the receiver], gathered straight into
 // MFMA registers as float4 pieces (half-wave h takes floats 8c+4h..8c+4h+3 of every 8-float
 // chunk).  The weight rows (zero-padded to whole chunks) sit in LDS for the workgroup.  Each wave
-// walks kEdgeGroups groups; the indices of group g+2 and the rows of group g+1 are requested
-// before the MFMAs of group g, and the stores of group g are issued after those requests, so
-// a wave always has gathers in flight behind its matrix work.
-template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
+// walks kEdgeGroups groups; for UT = 1 the indices of group g+2 and the rows of group g+1 are
+// requested before the MFMAs of group g, and the stores of group g are issued after those
+// requests, so a wave always has gathers in flight behind its matrix work.
+template <int FE_CHUNKS, bool SENDER_ONLY, int UT>
 struct EdgeRows {
-  static constexpr int CH = FE_CHUNKS + (SENDER_ONLY ? 4 : 8);
+  static constexpr int CH = FE_CHUNKS + (SENDER_ONLY ? 4 : 8) * UT;
   float4 v[CH];
 };
 
-template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
+template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY, int UT>
 __device__ inline void gather_edge_rows(const float* __restrict__ xq, const float* __restrict__ ef, int f_e,
-                                        int64_t e, int2 sr, int lh,
-                                        EdgeRows<FE_CHUNKS, FE_VEC, SENDER_ONLY>& rows) {
+                                        int64_t e, int2 sr, int lh, EdgeRows<FE_CHUNKS, SENDER_ONLY, UT>& rows) {
+  constexpr int U = 128 * UT, SC = 4 * UT;   // sender / receiver chunks of 8 floats
   if (FE_CHUNKS > 0) {
     if (FE_VEC) {
       const float4* pf = reinterpret_cast<const float4*>(ef + e * f_e) + lh;
@@ -812,22 +809,24 @@ __device__ inline void gather_edge_rows(const float* __restrict__ xq, const floa
       }
     }
   }
-  const float4* ps = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.x) * kUnits) + lh;
+  const float4* ps = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.x) * U) + lh;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) rows.v[FE_CHUNKS + c] = ps[2 * c];
+  for (int c = 0; c < SC; ++c) rows.v[FE_CHUNKS + c] = ps[2 * c];
   if (!SENDER_ONLY) {
-    const float4* pr = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.y) * kUnits) + lh;
+    const float4* pr = reinterpret_cast<const float4*>(xq + static_cast<int64_t>(sr.y) * U) + lh;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) rows.v[FE_CHUNKS + 4 + c] = pr[2 * c];
+    for (int c = 0; c < SC; ++c) rows.v[FE_CHUNKS + SC + c] = pr[2 * c];
   }
 }
 
-template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY>
+template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY, int UT>
 __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
-  using Rows = EdgeRows<FE_CHUNKS, FE_VEC, SENDER_ONLY>;
+  using Rows = EdgeRows<FE_CHUNKS, SENDER_ONLY, UT>;
   constexpr int CH = Rows::CH;
-  __shared__ float Ws[CH * 8 * kU];
-  __shared__ float red[4 * kU];
+  constexpr int U = 128 * UT, u = 32 * UT;
+  constexpr bool PIPE = UT == 1;   // two row buffers fit the register file only at u = 32
+  __shared__ float Ws[CH * 8 * u];
+  __shared__ float red[4 * u];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -835,123 +834,152 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
   const int64_t b = blockIdx.z;
   const int n_edges = a.n_edges[q];
   const int64_t block_base = static_cast<int64_t>(blockIdx.x) * kEdgesPerBlock;
-  float colsum = 0.0f;
+  float colsum[UT];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) colsum[t] = 0.0f;
 
   if (block_base < n_edges) {   // uniform over the workgroup
     const float* w = a.edge_w[q];
-    for (int i = tid; i < CH * 8 * kU; i += kThreads) {
-      const int row = i >> 5, col = i & 31;
+    for (int i = tid; i < CH * 8 * u; i += kThreads) {
+      const int row = i / u, col = i % u;
       float v;
       if (row < 8 * FE_CHUNKS)
-        v = row < a.f_e ? w[row * kU + col] : 0.0f;
+        v = row < a.f_e ? w[row * u + col] : 0.0f;
       else
-        v = w[(a.f_e + row - 8 * FE_CHUNKS) * kU + col];
+        v = w[(a.f_e + row - 8 * FE_CHUNKS) * u + col];
       Ws[i] = v;
     }
     __syncthreads();
-    const float bias = a.ebias[(b * 4 + q) * kU + li];
+    float bias[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) bias[t] = a.ebias[(b * 4 + q) * u + 32 * t + li];
     const int2* ei = reinterpret_cast<const int2*>(a.edge_index[q]);
-    const float* xq = a.xq + b * a.n_nodes * static_cast<int64_t>(kUnits) + kU * q;
+    const float* xq = a.xq + b * a.n_nodes * static_cast<int64_t>(U) + u * q;
     const float* ef = a.efeat[q] ? a.efeat[q] + b * n_edges * static_cast<int64_t>(a.f_e) : nullptr;
-    float* out = a.out[q] + b * n_edges * static_cast<int64_t>(kU);
+    float* out = a.out[q] + b * n_edges * static_cast<int64_t>(u);
     const int64_t wave_base = block_base + static_cast<int64_t>(wave) * kEdgeGroups * 32;
     auto edge_of = [&](int grp) {
       const int64_t e = wave_base + grp * 32 + li;
       return e < n_edges ? e : static_cast<int64_t>(n_edges) - 1;   // clamped lanes are masked at the store
     };
-
-    // One group: request the rows of group grp+1 into `nxt` (its indices were fetched a step
-    // earlier) and the indices of group grp+2, then multiply the rows of group grp held in `cur`.
-    // The two row buffers swap roles every step (no register copies, which would have to wait
-    // for the loads they copy).  FULL = every edge of the wave's groups exists: no clamps, no
-    // masks and no branches, so the whole sweep is one basic block and the requests stay where
-    // they are written, ahead of the matrix work of the previous group.
-    auto step = [&](auto full_tag, int grp, Rows& cur, Rows& nxt, int2& sr_nxt, int2& sr_nxt2) {
+    // the matrix work and the stores of one group whose rows are in `cur`
+    auto multiply = [&](auto full_tag, int64_t e0, const Rows& cur) {
       constexpr bool FULL = decltype(full_tag)::value;
-      const int64_t e0 = wave_base + grp * 32;
-      if (grp + 1 < kEdgeGroups && (FULL || e0 + 32 < n_edges)) {
-        if (grp + 2 < kEdgeGroups) sr_nxt2 = ei[FULL ? e0 + 64 + li : edge_of(grp + 2)];
-        gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY>(xq, ef, a.f_e, FULL ? e0 + 32 + li : edge_of(grp + 1),
-                                                         sr_nxt, lh, nxt);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the requests above the matrix work
-      f32x16 acc;
+      f32x16 acc[UT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const float a4[4] = {cur.v[c].x, cur.v[c].y, cur.v[c].z, cur.v[c].w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], Ws[(8 * c + 4 * lh + j) * kU + li], acc, 0, 0, 0);
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], Ws[(8 * c + 4 * lh + j) * u + 32 * t + li],
+                                                          acc[t], 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = e0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = activate(acc[r] + bias, a.relu);
         if (FULL || row < n_edges) {
-          out[row * kU + li] = v * a.out_scale;
-          colsum += v;
+#pragma unroll
+          for (int t = 0; t < UT; ++t) {
+            const float v = activate(acc[t][r] + bias[t], a.relu);
+            out[row * u + 32 * t + li] = v * a.out_scale;
+            colsum[t] += v;
+          }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     };
-    Rows r0, r1;
-    int2 sr_a, sr_b;
-    if (wave_base + kEdgeGroups * 32 <= n_edges) {
-      sr_a = ei[wave_base + 32 + li];
-      gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY>(xq, ef, a.f_e, wave_base + li, ei[wave_base + li], lh, r0);
+    if constexpr (PIPE) {
+      // One group: request the rows of group grp+1 into `nxt` (its indices were fetched a step
+      // earlier) and the indices of group grp+2, then multiply the rows of group grp held in
+      // `cur`.  The two row buffers swap roles every step (no register copies, which would have
+      // to wait for the loads they copy).  FULL = every edge of the wave's groups exists: no
+      // clamps, no masks and no branches, so the whole sweep is one basic block and the requests
+      // stay where they are written, ahead of the matrix work of the previous group.
+      auto step = [&](auto full_tag, int grp, Rows& cur, Rows& nxt, int2& sr_nxt, int2& sr_nxt2) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t e0 = wave_base + grp * 32;
+        if (grp + 1 < kEdgeGroups && (FULL || e0 + 32 < n_edges)) {
+          if (grp + 2 < kEdgeGroups) sr_nxt2 = ei[FULL ? e0 + 64 + li : edge_of(grp + 2)];
+          gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, FULL ? e0 + 32 + li : edge_of(grp + 1),
+                                                               sr_nxt, lh, nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests above the matrix work
+        multiply(full_tag, e0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      Rows r0, r1;
+      int2 sr_a, sr_b;
+      if (wave_base + kEdgeGroups * 32 <= n_edges) {
+        sr_a = ei[wave_base + 32 + li];
+        gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, wave_base + li, ei[wave_base + li], lh, r0);
 #pragma unroll
-      for (int grp = 0; grp < kEdgeGroups; grp += 2) {
-        step(std::true_type{}, grp, r0, r1, sr_a, sr_b);
-        step(std::true_type{}, grp + 1, r1, r0, sr_b, sr_a);
+        for (int grp = 0; grp < kEdgeGroups; grp += 2) {
+          step(std::true_type{}, grp, r0, r1, sr_a, sr_b);
+          step(std::true_type{}, grp + 1, r1, r0, sr_b, sr_a);
+        }
+      } else if (wave_base < n_edges) {
+        sr_a = ei[edge_of(1)];
+        gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, edge_of(0), ei[edge_of(0)], lh, r0);
+        for (int grp = 0; grp < kEdgeGroups && wave_base + grp * 32 < n_edges; grp += 2) {
+          step(std::false_type{}, grp, r0, r1, sr_a, sr_b);
+          if (wave_base + (grp + 1) * 32 < n_edges) step(std::false_type{}, grp + 1, r1, r0, sr_b, sr_a);
+        }
       }
-    } else if (wave_base < n_edges) {
-      sr_a = ei[edge_of(1)];
-      gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY>(xq, ef, a.f_e, edge_of(0), ei[edge_of(0)], lh, r0);
-      for (int grp = 0; grp < kEdgeGroups && wave_base + grp * 32 < n_edges; grp += 2) {
-        step(std::false_type{}, grp, r0, r1, sr_a, sr_b);
-        if (wave_base + (grp + 1) * 32 < n_edges) step(std::false_type{}, grp + 1, r1, r0, sr_b, sr_a);
+    } else {
+      for (int grp = 0; grp < kEdgeGroups && wave_base + grp * 32 < n_edges; ++grp) {
+        Rows cur;
+        gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, edge_of(grp), ei[edge_of(grp)], lh, cur);
+        multiply(std::false_type{}, wave_base + grp * 32, cur);
       }
     }
   }
-  colsum += __shfl_xor(colsum, 32);
-  if (lh == 0) red[wave * kU + li] = colsum;
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+    colsum[t] += __shfl_xor(colsum[t], 32);
+    if (lh == 0) red[wave * u + 32 * t + li] = colsum[t];
+  }
   __syncthreads();
-  if (tid < kU) {
-    const float s = ((red[tid] + red[kU + tid]) + red[2 * kU + tid]) + red[3 * kU + tid];
-    a.partial[((b * 4 + q) * gridDim.x + blockIdx.x) * kU + tid] = s;
+  if (tid < u) {
+    const float s = ((red[tid] + red[u + tid]) + red[2 * u + tid]) + red[3 * u + tid];
+    a.partial[((b * 4 + q) * gridDim.x + blockIdx.x) * u + tid] = s;
   }
 }
 
 struct AggArgs {
   const int32_t* rowptr[4];
   const int32_t* perm[4];
-  const float* msg[4];   // [B, E_q, 32]
+  const float* msg[4];   // [B, E_q, u]
   int n_edges[4];
   int n_nodes;
   float scale;
-  float* agg;            // [B, N, 128]
+  float* agg;            // [B, N, U]
 };
 
-// Receiver-CSR aggregation (unsorted_segment_sum, hybrid_gnn.py:110-113): 32 lanes own one
-// receiver's 128 output floats, 8 lanes x float4 per direction; messages are added in the
+// Receiver-CSR aggregation (unsorted_segment_sum, hybrid_gnn.py:110-113): 32*UT lanes own one
+// receiver's U output floats, 8*UT lanes x float4 per direction; messages are added in the
 // reference's edge order, starting from zero, then scaled.
+template <int UT>
 __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
+  constexpr int U = 128 * UT, u = 32 * UT, LPN = 32 * UT, LPQ = 8 * UT;   // lanes per node / direction
   const int tid = threadIdx.x;
-  const int64_t v = static_cast<int64_t>(blockIdx.x) * (kThreads / 32) + (tid >> 5);
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * (kThreads / LPN) + tid / LPN;
   if (v >= a.n_nodes) return;
   const int64_t b = blockIdx.y;
-  const int sub = tid & 31, q = sub >> 3, c4 = sub & 7;
+  const int sub = tid % LPN, q = sub / LPQ, c4 = sub % LPQ;
   const int32_t* rowptr = q == 0 ? a.rowptr[0] : q == 1 ? a.rowptr[1] : q == 2 ? a.rowptr[2] : a.rowptr[3];
   const int32_t* perm = q == 0 ? a.perm[0] : q == 1 ? a.perm[1] : q == 2 ? a.perm[2] : a.perm[3];
   const float* msg = q == 0 ? a.msg[0] : q == 1 ? a.msg[1] : q == 2 ? a.msg[2] : a.msg[3];
   const int ne = q == 0 ? a.n_edges[0] : q == 1 ? a.n_edges[1] : q == 2 ? a.n_edges[2] : a.n_edges[3];
-  msg += b * ne * static_cast<int64_t>(kU) + 4 * c4;
+  msg += b * ne * static_cast<int64_t>(u) + 4 * c4;
   const int beg = rowptr[v], end = rowptr[v + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int s = beg; s < end; ++s) {
-    const float4 m = *reinterpret_cast<const float4*>(msg + static_cast<int64_t>(perm[s]) * kU);
+    const float4 m = *reinterpret_cast<const float4*>(msg + static_cast<int64_t>(perm[s]) * u);
     acc.x += m.x;
     acc.y += m.y;
     acc.z += m.z;
@@ -961,32 +989,36 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
   acc.y *= a.scale;
   acc.z *= a.scale;
   acc.w *= a.scale;
-  *reinterpret_cast<float4*>(a.agg + (b * a.n_nodes + v) * kUnits + kU * q + 4 * c4) = acc;
+  *reinterpret_cast<float4*>(a.agg + (b * a.n_nodes + v) * U + u * q + 4 * c4) = acc;
 }
 
 // Per sample: finish the node / edge column sums (fp64 accumulation over the per-tile partials:
-// 32 thread subsets take tiles sub, sub + 32, ... with float4 loads, the subsets are then added in
+// the thread subsets take tiles sub, sub + S, ... with float4 loads, the subsets are then added in
 // order), scale them and apply the global transform (hybrid_gnn.py:130-135).
+template <int UT>
 __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
                                                                  const float* __restrict__ global_in,
                                                                  const float* __restrict__ npart, int n_nblk,
                                                                  const float* __restrict__ epart, int n_eblk,
                                                                  int relu, float* __restrict__ global_out) {
+  constexpr int U = 128 * UT, u = 32 * UT;
+  constexpr int QC = U / 4, S = kSmallThreads / QC;
+  constexpr int EG = kSmallThreads / U;
   extern __shared__ __attribute__((aligned(16))) float gsh[];
-  double* dpart = reinterpret_cast<double*>(gsh);                      // [32][128]
-  float* part4 = reinterpret_cast<float*>(dpart + kSubsets * kUnits);  // [32][128]
-  float* gin = part4 + kSubsets * kUnits;                              // [g + 128 + 32]
+  double* dpart = reinterpret_cast<double*>(gsh);          // 4096 doubles
+  float* part = reinterpret_cast<float*>(dpart + 4096);    // 4096 floats
+  float* gin = part + 4096;                                // [g + U + u]
   const int tid = threadIdx.x;
-  const int sub = tid >> 5, cq = tid & 31;
+  const int sub = tid / QC, cq = tid % QC;
   const int64_t b = blockIdx.x;
   for (int k = tid; k < p.g; k += blockDim.x) gin[k] = global_in[b * p.g + k];
   {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const float4* src = reinterpret_cast<const float4*>(npart + b * n_nblk * static_cast<int64_t>(kUnits)) + cq;
+    const float4* src = reinterpret_cast<const float4*>(npart + b * n_nblk * static_cast<int64_t>(U)) + cq;
     int i = sub;
-    for (; i + kSubsets < n_nblk; i += 2 * kSubsets) {
-      const float4 a = src[static_cast<int64_t>(i) * kQuadCols];
-      const float4 c = src[static_cast<int64_t>(i + kSubsets) * kQuadCols];
+    for (; i + S < n_nblk; i += 2 * S) {
+      const float4 a = src[static_cast<int64_t>(i) * QC];
+      const float4 c = src[static_cast<int64_t>(i + S) * QC];
       s0 += static_cast<double>(a.x);
       s1 += static_cast<double>(a.y);
       s2 += static_cast<double>(a.z);
@@ -996,57 +1028,57 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
       s2 += static_cast<double>(c.z);
       s3 += static_cast<double>(c.w);
     }
-    for (; i < n_nblk; i += kSubsets) {
-      const float4 a = src[static_cast<int64_t>(i) * kQuadCols];
+    for (; i < n_nblk; i += S) {
+      const float4 a = src[static_cast<int64_t>(i) * QC];
       s0 += static_cast<double>(a.x);
       s1 += static_cast<double>(a.y);
       s2 += static_cast<double>(a.z);
       s3 += static_cast<double>(a.w);
     }
-    double* d = dpart + sub * kUnits + 4 * cq;
+    double* d = dpart + sub * U + 4 * cq;
     d[0] = s0;
     d[1] = s1;
     d[2] = s2;
     d[3] = s3;
   }
   __syncthreads();
-  if (tid < kUnits) {
+  if (tid < U) {
     double s = dpart[tid];
-    for (int g = 1; g < kSubsets; ++g) s += dpart[g * kUnits + tid];
+    for (int g = 1; g < S; ++g) s += dpart[g * U + tid];
     const float denom = p.gsn * 300.0f * 300.0f;
     gin[p.g + tid] = (static_cast<float>(s) * 1.0f) / denom;
   }
   __syncthreads();
   {
-    // message sums: [4 directions][n_eblk][32]; thread (grp, col) with col = 32*q + c
-    const int grp = tid >> 7, col = tid & 127;
-    const int q = col >> 5, c = col & 31;
+    // message sums: [4 directions][n_eblk][u]; thread (grp, col) with col = u*q + c
+    const int grp = tid / U, col = tid % U;
+    const int q = col / u, c = col % u;
     double s = 0.0;
-    const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(kU) + c;
-    for (int i = grp; i < n_eblk; i += kGroups) s += static_cast<double>(src[static_cast<int64_t>(i) * kU]);
-    dpart[grp * kUnits + col] = s;
+    const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(u) + c;
+    for (int i = grp; i < n_eblk; i += EG) s += static_cast<double>(src[static_cast<int64_t>(i) * u]);
+    dpart[grp * U + col] = s;
   }
   __syncthreads();
-  if (tid < kU) {
+  if (tid < u) {
     float total = 0.0f;
     for (int q = 0; q < 4; ++q) {
-      double s = dpart[q * kU + tid];
-      for (int g = 1; g < kGroups; ++g) s += dpart[g * kUnits + q * kU + tid];
+      double s = dpart[q * u + tid];
+      for (int g = 1; g < EG; ++g) s += dpart[g * U + q * u + tid];
       total += static_cast<float>(s);
     }
     const float denom = p.gse * 300.0f * 300.0f * 8.0f;
-    gin[p.g + kUnits + tid] = (total * 1.0f) / denom;
+    gin[p.g + U + tid] = (total * 1.0f) / denom;
   }
   __syncthreads();
-  const int kin = p.g + kUnits + kU;
+  const int kin = p.g + U + u;
   if (p.globt_w != nullptr) {
-    const float4 s = matvec_partial(gin, p.globt_w, kin, sub, cq);
-    *reinterpret_cast<float4*>(&part4[sub * kUnits + 4 * cq]) = s;
+    const float4 s = matvec_partial<U>(gin, p.globt_w, kin, sub, cq);
+    *reinterpret_cast<float4*>(&part[sub * U + 4 * cq]) = s;
     __syncthreads();
-    if (tid < kUnits) {
-      float t = combine_subsets(part4, tid);
+    if (tid < U) {
+      float t = combine_rows(part, S, U, tid);
       if (p.globt_b) t += p.globt_b[tid];
-      global_out[b * kUnits + tid] = activate(t, relu);
+      global_out[b * U + tid] = activate(t, relu);
     }
   } else {
     for (int k = tid; k < kin; k += blockDim.x) global_out[b * kin + k] = gin[k];
@@ -1056,13 +1088,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct LayerWorkspace {
-  float* xq;      // [B, N, 128]            node embeddings (generic) / coarse rows only (upsample)
-  float* agg;     // [B, N, 128]            aggregated messages (generic) / messages [B, N_fine, 32]
-  float* nbias;   // [128]
-  float* ebias;   // [B, 128]
-  float* gbias;   // [B, 128]
-  float* npart;   // [B, n_nblk, 128]
-  float* epart;   // [B, 4, n_eblk, 32]
+  float* xq;      // [B, N, U]            node embeddings (generic) / coarse rows only (upsample)
+  float* agg;     // [B, N, U]            aggregated messages (generic) / messages [B, N_fine, u]
+  float* nbias;   // [U]
+  float* ebias;   // [B, U]
+  float* gbias;   // [B, U]
+  float* npart;   // [B, n_nblk + 5, U]
+  float* epart;   // [B, 4, n_eblk, u]
   void* wpack;    // weight image of the GEMM in flight (split-bf16 matmul modes)
   int n_nblk, n_eblk;
   size_t bytes;
@@ -1070,9 +1102,9 @@ struct LayerWorkspace {
 
 // One layout serves both entry points: the upsampling form needs at most 4 node tiles more than
 // the generic one (one partly filled tile per quadrant) and less of everything else.
-LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, void* base) {
+LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int units, void* base) {
   LayerWorkspace ws;
-  const size_t n = static_cast<size_t>(g->n_nodes), bsz = static_cast<size_t>(batch);
+  const size_t n = static_cast<size_t>(g->n_nodes), bsz = static_cast<size_t>(batch), U = units, u = units / 4;
   int max_e = 0;
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
   ws.n_nblk = static_cast<int>(ceil_div(g->n_nodes, kBM));
@@ -1083,14 +1115,14 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, void* ba
     off = align_up(off + floats * sizeof(float), 256);
     return p;
   };
-  ws.xq = take(bsz * n * kUnits);
-  ws.agg = take(bsz * n * kUnits);
-  ws.nbias = take(kUnits);
-  ws.ebias = take(bsz * kUnits);
-  ws.gbias = take(bsz * kUnits);
-  ws.npart = take(bsz * (ws.n_nblk + 5) * kUnits);
-  ws.epart = take(bsz * 4 * ws.n_eblk * kU);
-  ws.wpack = take(wpack_bytes(kMaxKTiles, 4) / sizeof(float));
+  ws.xq = take(bsz * n * U);
+  ws.agg = take(bsz * n * U);
+  ws.nbias = take(U);
+  ws.ebias = take(bsz * U);
+  ws.gbias = take(bsz * U);
+  ws.npart = take(bsz * (ws.n_nblk + 5) * U);
+  ws.epart = take(bsz * 4 * ws.n_eblk * u);
+  ws.wpack = take(wpack_bytes((kMaxCin + 128 * kMaxUT) / kBK + 2, 4) / sizeof(float));
   ws.bytes = off;
   return ws;
 }
@@ -1101,8 +1133,8 @@ int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_g
   GUNET_REQUIRE(batch > 0, "%s: batch must be positive", fn);
   GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU, "%s: unknown activation %d",
                 fn, activation);
-  if (w->units != kUnits) {
-    set_error("%s: units = %d is not implemented (only %d)", fn, w->units, kUnits);
+  if (w->units != 128 && w->units != 256) {
+    set_error("%s: units = %d is not implemented (128 and 256 are)", fn, w->units);
     return GUNET_ERR_UNSUPPORTED;
   }
   GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0 && w->c_in <= kMaxCin,
@@ -1121,7 +1153,7 @@ int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_g
       GUNET_REQUIRE(graph->edge_index[q] && graph->perm[q], "%s: null edge list for direction %d", fn, q);
     GUNET_REQUIRE(graph->n_nodes == 0 || graph->rowptr[q], "%s: null rowptr for direction %d", fn, q);
   }
-  *ws = carve_workspace(graph, batch, const_cast<void*>(workspace));
+  *ws = carve_workspace(graph, batch, w->units, const_cast<void*>(workspace));
   if (workspace == nullptr || workspace_bytes < ws->bytes) {
     set_error("%s: workspace of %zu bytes is smaller than the %zu required", fn, workspace_bytes, ws->bytes);
     return GUNET_ERR_WORKSPACE;
@@ -1151,26 +1183,60 @@ LayerPtrs layer_ptrs(const gunet_gn_weights* w) {
   return p;
 }
 
-int launch_prologue(const LayerPtrs& p, const float* global_in, int relu, int fold_receiver, int32_t batch,
-                    const LayerWorkspace& ws, hipStream_t stream) {
+int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu, int fold_receiver,
+                    int32_t batch, const LayerWorkspace& ws, hipStream_t stream) {
   ProfScope prof(kProfPrologue, stream);
-  k_layer_prologue<<<batch, kSmallThreads, sizeof(float) * (kSubsets * kUnits + p.g + 4 * kU), stream>>>(
-      p, global_in, relu, fold_receiver, ws.nbias, ws.ebias, ws.gbias);
+  const size_t lds = sizeof(float) * (4096 + p.g + 4 * 32 * ut);
+  if (ut == 1)
+    k_layer_prologue<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver, ws.nbias,
+                                                                 ws.ebias, ws.gbias);
+  else
+    k_layer_prologue<2><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver, ws.nbias,
+                                                                 ws.ebias, ws.gbias);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
-int launch_global_update(const LayerPtrs& p, const float* global_in, int n_nblk, int relu, int32_t batch,
-                         const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
+int launch_global_update(const LayerPtrs& p, int ut, const float* global_in, int n_nblk, int relu,
+                         int32_t batch, const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
   ProfScope prof(kProfGlobalUpdate, stream);
-  k_global_update<<<batch, kSmallThreads,
-                    sizeof(double) * kSubsets * kUnits + sizeof(float) * (kSubsets * kUnits + p.g + kUnits + kU),
-                    stream>>>(p, global_in, ws.npart, n_nblk, ws.epart, ws.n_eblk, relu, global_out);
+  const size_t lds = sizeof(double) * 4096 + sizeof(float) * (4096 + p.g + 160 * ut);
+  if (ut == 1)
+    k_global_update<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, ws.npart, n_nblk, ws.epart,
+                                                                ws.n_eblk, relu, global_out);
+  else
+    k_global_update<2><<<batch, kSmallThreads, lds, stream>>>(p, global_in, ws.npart, n_nblk, ws.epart,
+                                                                ws.n_eblk, relu, global_out);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
-int launch_edge_mlp(EdgeArgs& a, const gunet_quadgraph* graph, const float* const edges[4], int n_eblk,
+template <int UT>
+int launch_edge_mlp_ut(EdgeArgs& a, int chunks, bool vec, dim3 grid, hipStream_t stream) {
+  if (a.sender_only) {
+    k_edge_mlp<0, false, true, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks == 0) {
+    k_edge_mlp<0, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (vec && chunks == 2) {
+    k_edge_mlp<2, true, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (vec && chunks == 4) {
+    k_edge_mlp<4, true, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (vec && chunks == 8) {
+    k_edge_mlp<8, true, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks == 1) {
+    k_edge_mlp<1, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks == 2) {
+    k_edge_mlp<2, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else if (chunks <= 4) {
+    k_edge_mlp<4, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  } else {
+    k_edge_mlp<8, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+  }
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const float* const edges[4], int n_eblk,
                     int32_t batch, hipStream_t stream) {
   bool any_feat = false, all_feat = true, vec_ok = a.f_e % 8 == 0;
   for (int q = 0; q < 4; ++q) {
@@ -1190,28 +1256,32 @@ int launch_edge_mlp(EdgeArgs& a, const gunet_quadgraph* graph, const float* cons
   dim3 grid(static_cast<unsigned>(n_eblk), 4, static_cast<unsigned>(batch));
   ProfScope prof(kProfEdgeMlp, stream);
   const int chunks = (!any_feat || a.f_e == 0) ? 0 : (a.f_e + 7) / 8;
-  if (a.sender_only) {
-    if (chunks != 0) {
-      set_error("edge_mlp: the sender-only form takes no edge features");
-      return GUNET_ERR_INVALID;
-    }
-    k_edge_mlp<0, false, true><<<grid, kThreads, 0, stream>>>(a);
-  } else if (chunks == 0) {
-    k_edge_mlp<0, false, false><<<grid, kThreads, 0, stream>>>(a);
-  } else if (vec_ok && all_feat && chunks == 2) {
-    k_edge_mlp<2, true, false><<<grid, kThreads, 0, stream>>>(a);
-  } else if (vec_ok && all_feat && chunks == 4) {
-    k_edge_mlp<4, true, false><<<grid, kThreads, 0, stream>>>(a);
-  } else if (chunks == 1) {
-    k_edge_mlp<1, false, false><<<grid, kThreads, 0, stream>>>(a);
-  } else if (chunks == 2) {
-    k_edge_mlp<2, false, false><<<grid, kThreads, 0, stream>>>(a);
-  } else if (chunks <= 4) {
-    k_edge_mlp<4, false, false><<<grid, kThreads, 0, stream>>>(a);
-  } else {
-    k_edge_mlp<8, false, false><<<grid, kThreads, 0, stream>>>(a);
+  if (a.sender_only && chunks != 0) {
+    set_error("edge_mlp: the sender-only form takes no edge features");
+    return GUNET_ERR_INVALID;
   }
-  GUNET_LAUNCH_CHECK();
+  return ut == 1 ? launch_edge_mlp_ut<1>(a, chunks, vec_ok && all_feat, grid, stream)
+                 : launch_edge_mlp_ut<2>(a, chunks, vec_ok && all_feat, grid, stream);
+}
+
+// GEMM with U output columns as U/128 launches of 128 columns.  `w_of(col)` gives the weight
+// pointer of the 32-column tile starting at output column `col` for segment s.
+template <typename WeightOf>
+int launch_gemm_columns(GemmArgs g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
+                        float* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
+  for (int col0 = 0; col0 < units; col0 += 128) {
+    GemmArgs gc = g;
+    for (int s = 0; s < g.n_seg; ++s)
+      for (int t = 0; t < 4; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
+    gc.bias = bias ? bias + col0 : nullptr;
+    gc.bias_stride = bias_stride;
+    gc.out = out;
+    gc.ldo = units;
+    gc.out_col0 = col0;
+    gc.colsum = colsum;
+    gc.colsum_ld = units;
+    GUNET_TRY(launch_gemm(gc, 4, batch, wpack, stream));
+  }
   return GUNET_OK;
 }
 
@@ -1328,8 +1398,8 @@ int gunet_set_matmul_mode(int mode) {
 int gunet_get_matmul_mode(void) { return g_matmul_mode; }
 
 size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batch, int32_t units) {
-  if (graph == nullptr || batch <= 0 || units != kUnits) return 0;
-  return carve_workspace(graph, batch, nullptr).bytes;
+  if (graph == nullptr || batch <= 0 || (units != 128 && units != 256)) return 0;
+  return carve_workspace(graph, batch, units, nullptr).bytes;
 }
 
 int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch,
@@ -1350,32 +1420,29 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_REQUIRE(graph->n_edges[q] == 0 || edges_out[q], "gn_layer: null edges_out[%d]", q);
   const int relu = activation == GUNET_ACT_RELU;
   const int n = graph->n_nodes;
+  const int U = w->units, u = U / 4, ut = U / 128;
   const int c_a = w->c_in - c_skip;          // width of x; x_skip supplies the remaining columns
   const LayerPtrs p = layer_ptrs(w);
 
-  GUNET_TRY(launch_prologue(p, global_in, relu, 0, batch, ws, stream));
+  GUNET_TRY(launch_prologue(p, ut, global_in, relu, 0, batch, ws, stream));
 
-  {  // node embeddings of the four directions in one GEMM (hybrid_gnn.py:91-92)
+  {  // node embeddings of the four directions in one GEMM per 128 columns (hybrid_gnn.py:91-92)
     GemmArgs g = {};
     g.n_seg = c_skip ? 2 : 1;
     g.seg[0].a = x;
     g.seg[0].lda = c_a;
     g.seg[0].k = c_a;
-    g.seg[0].ldw = kU;
+    g.seg[0].ldw = u;
     g.seg[1].a = x_skip;
     g.seg[1].lda = c_skip;
     g.seg[1].k = c_skip;
-    g.seg[1].ldw = kU;
-    for (int q = 0; q < 4; ++q) {
-      g.seg[0].w[q] = w->node_emb_w[q];
-      g.seg[1].w[q] = w->node_emb_w[q] + static_cast<int64_t>(c_a) * kU;
-    }
+    g.seg[1].ldw = u;
     g.n_rows = n;
-    g.bias = ws.nbias;
-    g.out = ws.xq;
-    g.ldo = kUnits;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
+    auto w_of = [&](int s, int col) {
+      return w->node_emb_w[col / u] + (s == 0 ? 0 : static_cast<int64_t>(c_a) * u) + col % u;
+    };
+    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.nbias, 0, ws.xq, nullptr, w_of, ws.wpack, stream));
   }
 
   {  // edge MLP + message column sums (hybrid_gnn.py:93-108)
@@ -1391,7 +1458,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     a.partial = ws.epart;
     a.relu = relu;
     a.out_scale = 1.0f;
-    GUNET_TRY(launch_edge_mlp(a, graph, edges, ws.n_eblk, batch, stream));
+    GUNET_TRY(launch_edge_mlp(a, ut, graph, edges, ws.n_eblk, batch, stream));
   }
 
   if (n > 0) {  // neighbour aggregation (hybrid_gnn.py:110-113)
@@ -1405,45 +1472,42 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     a.n_nodes = n;
     a.scale = 1.0f / (3 + 1);
     a.agg = ws.agg;
-    dim3 grid(static_cast<unsigned>(ceil_div(n, kThreads / 32)), static_cast<unsigned>(batch));
+    dim3 grid(static_cast<unsigned>(ceil_div(n, kThreads / (32 * ut))), static_cast<unsigned>(batch));
     ProfScope prof(kProfAggregate, stream);
-    k_aggregate<<<grid, kThreads, 0, stream>>>(a);
+    if (ut == 1)
+      k_aggregate<1><<<grid, kThreads, 0, stream>>>(a);
+    else
+      k_aggregate<2><<<grid, kThreads, 0, stream>>>(a);
     GUNET_LAUNCH_CHECK();
   }
 
   {  // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
     GemmArgs g = {};
     int s = 0;
+    int64_t row_of[3];
     g.seg[s].a = x;
     g.seg[s].lda = c_a;
     g.seg[s].k = c_a;
-    for (int t = 0; t < 4; ++t) g.seg[s].w[t] = w->node_w + 32 * t;
-    ++s;
+    row_of[s++] = 0;
     if (c_skip) {
       g.seg[s].a = x_skip;
       g.seg[s].lda = c_skip;
       g.seg[s].k = c_skip;
-      for (int t = 0; t < 4; ++t) g.seg[s].w[t] = w->node_w + static_cast<int64_t>(c_a) * kUnits + 32 * t;
-      ++s;
+      row_of[s++] = c_a;
     }
     g.seg[s].a = ws.agg;
-    g.seg[s].lda = kUnits;
-    g.seg[s].k = kUnits;
-    for (int t = 0; t < 4; ++t) g.seg[s].w[t] = w->node_w + static_cast<int64_t>(w->c_in) * kUnits + 32 * t;
-    ++s;
+    g.seg[s].lda = U;
+    g.seg[s].k = U;
+    row_of[s++] = w->c_in;
     g.n_seg = s;
-    for (int i = 0; i < s; ++i) g.seg[i].ldw = kUnits;
+    for (int i = 0; i < s; ++i) g.seg[i].ldw = U;
     g.n_rows = n;
-    g.bias = ws.gbias;
-    g.bias_stride = kUnits;
-    g.out = x_out;
-    g.ldo = kUnits;
-    g.colsum = ws.npart;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
+    auto w_of = [&](int seg, int col) { return w->node_w + row_of[seg] * U + col; };
+    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
   }
 
-  return launch_global_update(p, global_in, n > 0 ? ws.n_nblk : 0, relu, batch, ws, global_out, stream);
+  return launch_global_update(p, ut, global_in, n > 0 ? ws.n_nblk : 0, relu, batch, ws, global_out, stream);
 }
 
 int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w,
@@ -1464,11 +1528,12 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
   GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0,
                 "gn_upsample: x and x_out must be 16-byte aligned");
   const int relu = activation == GUNET_ACT_RELU;
+  const int U = w->units, u = U / 4, ut = U / 128;
   const LayerPtrs p = layer_ptrs(w);
 
   // The layer input is [x ; 0]: rows n_coarse.. are zero, so their embedding is act(bias) for every
   // fine node; its product with the receiver rows of the edge kernel is folded into the edge bias.
-  GUNET_TRY(launch_prologue(p, global_in, relu, 1, batch, ws, stream));
+  GUNET_TRY(launch_prologue(p, ut, global_in, relu, 1, batch, ws, stream));
 
   {  // embeddings of the coarse rows only
     GemmArgs g = {};
@@ -1476,25 +1541,22 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     g.seg[0].a = x;
     g.seg[0].lda = w->c_in;
     g.seg[0].k = w->c_in;
-    g.seg[0].ldw = kU;
-    for (int q = 0; q < 4; ++q) g.seg[0].w[q] = w->node_emb_w[q];
+    g.seg[0].ldw = u;
     g.n_rows = n_coarse;
-    g.bias = ws.nbias;
-    g.out = ws.xq;
-    g.ldo = kUnits;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
+    auto w_of = [&](int, int col) { return w->node_emb_w[col / u] + col % u; };
+    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.nbias, 0, ws.xq, nullptr, w_of, ws.wpack, stream));
   }
 
   // messages: every edge goes (coarse parent -> fine node); edge features are zero.  Stored
-  // already scaled by 1/4, quadrant after quadrant, in ws.agg viewed as [B, n_fine, 32].
+  // already scaled by 1/4, quadrant after quadrant, in ws.agg viewed as [B, n_fine, u].
   float* msg[4];
   {
     int64_t off = 0;
     EdgeArgs a = {};
     for (int q = 0; q < 4; ++q) {
       msg[q] = ws.agg + off;
-      off += static_cast<int64_t>(batch) * graph->n_edges[q] * kU;
+      off += static_cast<int64_t>(batch) * graph->n_edges[q] * u;
       a.edge_w[q] = w->edge_w[q];
       a.out[q] = msg[q];
     }
@@ -1506,13 +1568,13 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     a.relu = relu;
     a.sender_only = 1;
     a.out_scale = 1.0f / (3 + 1);
-    GUNET_TRY(launch_edge_mlp(a, graph, nullptr, ws.n_eblk, batch, stream));
+    GUNET_TRY(launch_edge_mlp(a, ut, graph, nullptr, ws.n_eblk, batch, stream));
   }
 
   // node MLP.  Coarse rows: only the x columns are non-zero and only their column sums are used
   // (the rows themselves are dropped by the caller, hybrid_gnn.py:377).  Fine rows: x is zero and
   // the aggregate is the single incoming message in the columns of its quadrant, so each
-  // quadrant's edges are one K=32 GEMM scattered to the fine rows.
+  // quadrant's edges are one K=u GEMM scattered to the fine rows.
   const int tiles_c = static_cast<int>(ceil_div(n_coarse, kBM));
   int tiles_total = tiles_c;
   int tile0[4];
@@ -1526,45 +1588,34 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     g.seg[0].a = x;
     g.seg[0].lda = w->c_in;
     g.seg[0].k = w->c_in;
-    g.seg[0].ldw = kUnits;
-    for (int t = 0; t < 4; ++t) g.seg[0].w[t] = w->node_w + 32 * t;
+    g.seg[0].ldw = U;
     g.n_rows = n_coarse;
-    g.bias = ws.gbias;
-    g.bias_stride = kUnits;
-    g.out = nullptr;
-    g.ldo = kUnits;
-    g.colsum = ws.npart;
     g.colsum_tiles = tiles_total;
     g.colsum_tile0 = 0;
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
+    auto w_of = [&](int, int col) { return w->node_w + col; };
+    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, nullptr, ws.npart, w_of, ws.wpack, stream));
   }
   for (int q = 0; q < 4; ++q) {
     if (graph->n_edges[q] == 0) continue;
     GemmArgs g = {};
     g.n_seg = 1;
     g.seg[0].a = msg[q];
-    g.seg[0].lda = kU;
-    g.seg[0].k = kU;
-    g.seg[0].ldw = kUnits;
-    for (int t = 0; t < 4; ++t)
-      g.seg[0].w[t] = w->node_w + static_cast<int64_t>(w->c_in + kU * q) * kUnits + 32 * t;
+    g.seg[0].lda = u;
+    g.seg[0].k = u;
+    g.seg[0].ldw = U;
     g.n_rows = graph->n_edges[q];
-    g.bias = ws.gbias;
-    g.bias_stride = kUnits;
-    g.out = x_out;
-    g.ldo = kUnits;
     g.out_rows = n_fine;
     g.row_map = graph->edge_index[q] + 1;   // receiver column of the edge list
     g.row_map_stride = 2;
     g.row_map_sub = n_coarse;
-    g.colsum = ws.npart;
     g.colsum_tiles = tiles_total;
     g.colsum_tile0 = tile0[q];
     g.relu = relu;
-    GUNET_TRY(launch_gemm(g, 4, batch, ws.wpack, stream));
+    auto w_of = [&](int, int col) { return w->node_w + static_cast<int64_t>(w->c_in + u * q) * U + col; };
+    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
   }
-  return launch_global_update(p, global_in, tiles_total, relu, batch, ws, global_out, stream);
+  return launch_global_update(p, ut, global_in, tiles_total, relu, batch, ws, global_out, stream);
 }
 
 }  // extern "C"

@@ -493,6 +493,45 @@ def graph_unet_shapes(units=128, in_features=104, out_units=96, depth=3, f_e0=16
     return shapes
 
 
+def graph_unet_block_units(units, depth=3):
+    """Widths the constructor gives the blocks (models/graph_unet.py:37-55): in_layer and the
+    down blocks max(units * 2**i, 128), both bottleneck layers 128, the up blocks
+    max(units * 2**(depth - i - 1), 128)."""
+    down = [max(units * 2 ** i, 128) for i in range(depth)]
+    up = [max(units * 2 ** (depth - i - 1), 128) for i in range(depth)]
+    return max(units, 128), down, 128, up
+
+
+def graph_unet_shapes_for(units, in_features=104, out_units=96, depth=3, f_e0=16, g0=113):
+    """Variable name -> shape of GraphUNet(units, depth=depth) for any constructor `units`,
+    following the widths through models/graph_unet.py:60-84 (units <= 32 gives the shipped
+    checkpoint's uniform 128)."""
+    w_in, down, w_mid, up = graph_unet_block_units(units, depth)
+    shapes = {'in_layer/kernel': (in_features, w_in), 'in_layer/bias': (w_in,)}
+    c, f_e, g = w_in, f_e0, g0
+    skip_c, skip_fe, skip_g = [], [], []
+    for d in range(depth):
+        skip_c.append(c)
+        skip_fe.append(f_e)
+        skip_g.append(g)
+        shapes.update(gn_layer_shapes(f'downsampling_layers/{d}/gcns/0', c, f_e, g, down[d]))
+        c, f_e, g = down[d], down[d] // 4, down[d]
+    shapes.update(gn_layer_shapes('bottleneck_gcn_1', c, f_e, g, w_mid))
+    shapes.update(gn_layer_shapes('bottleneck_gcn_2', w_mid, w_mid // 4, w_mid, w_mid))
+    c, g = w_mid, w_mid
+    for d in range(depth):
+        lvl = depth - 1 - d
+        shapes.update(gn_layer_shapes(f'upsampling_layers/{d}/upsampling/gcn', c, 2, g + skip_g[lvl], up[d]))
+        shapes.update(gn_layer_shapes(f'upsampling_layers/{d}/gcns/0', up[d] + skip_c[lvl], skip_fe[lvl],
+                                      up[d], up[d]))
+        shapes.update(gn_layer_shapes(f'upsampling_layers/{d}/gcns/1', up[d], up[d] // 4, up[d], up[d],
+                                      with_glob_transform=d != depth - 1))
+        c, g = up[d], up[d]
+    # the last layer keeps the untransformed global (hybrid_gnn.py:70); nothing reads it afterwards
+    shapes['out_model/kernel'] = (c, out_units)
+    return shapes
+
+
 def make_weights(shapes, seed=1):
     """Glorot-uniform kernels, U(-0.1, 0.1) biases (non-zero so every bias path
     is exercised), global scales 1.0.  Deterministic in (shapes order, seed)."""
