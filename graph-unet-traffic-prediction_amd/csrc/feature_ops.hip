@@ -5,6 +5,7 @@
 //   * the GeoQuadrantGCN layer: four-direction node-embedding GEMM, gathered edge MLP on MFMA,
 //     receiver-CSR aggregation, node MLP GEMM and the small global-feature updates.
 // All reductions are atomic-free and run in a fixed order, so outputs are bitwise reproducible.
+#include <algorithm>
 #include <cfloat>
 #include <type_traits>
 
@@ -137,15 +138,16 @@ struct GemmArgs {
   const int32_t* row_map;     // A row r -> output row row_map[r * row_map_stride] - row_map_sub
   int row_map_stride;         //   (null = identity)
   int row_map_sub;
-  float* colsum;              // per-tile column sums of the activated output, or null:
-  int colsum_tiles;           //   [B][colsum_tiles][32*NT], this launch fills tiles
-  int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + gridDim.x - 1; row stride colsum_ld
+  float* colsum;              // column sums of the activated output per group of 32 rows, or null:
+  int colsum_tiles;           //   [B][colsum_tiles][colsum_ld], this launch fills groups
+  int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + ceil(n_rows / 32) - 1
   int colsum_ld;              //   floats (0 = 32*NT), this launch's columns start at out_col0
   int relu;
 };
 
 constexpr int kBM = 128;
 constexpr int kBK = 32;
+constexpr int kRowGroup = 32;   // rows of one wave = rows of one column-sum partial
 
 // The A operand goes straight from global memory into MFMA registers: lane (li, lh) of wave w
 // owns row 32w+li of the tile and reads floats 8c+4lh..8c+4lh+3 of every 8-float K chunk of that
@@ -153,12 +155,12 @@ constexpr int kBK = 32;
 // k of each MFMA; the k order inside a chunk is a fixed permutation, the same for the weights).
 // Only the weight tile goes through LDS (double-buffered, one barrier per K tile); the next A
 // tile is prefetched in registers.  Epilogue: bias, activation, optional row scatter, and the
-// per-tile column sums (fixed order: 16 rows per lane, half-waves, then the four waves).
+// column sums of every wave's 32 rows (fixed order: 16 rows per lane, then the two half-waves).
 template <int NT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
   constexpr int BN = 32 * NT;
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BN];
-  __shared__ float red[4 * BN];
+  __shared__ __attribute__((aligned(16))) float Stage[4][16 * 32];   // epilogue: one per wave
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -255,33 +257,247 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
   }
 
   // accumulator register r of lane (li, lh) is row (r&3) + 8*(r>>2) + 4*lh of the wave, column li
-  float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + g.out_col0 + li : nullptr;
   float cs[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) cs[n] = 0.0f;
+  const int wrow0 = row0 + 32 * wave;
+  if (g.row_map == nullptr) {
+    // 16 rows x 32 columns at a time through the wave's own LDS, picked up row-wise: a store
+    // instruction then writes eight full 128-byte lines instead of two
+    float* stage = Stage[wave];
+    const int srow = lane >> 3, scol = 4 * (lane & 7);
+    float* obase = g.out ? g.out + (b * g.out_rows + wrow0 + srow) * static_cast<int64_t>(g.ldo) + g.out_col0 + scol
+                         : nullptr;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (row < g.n_rows) {
-      const int64_t orow = g.row_map ? g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub : row;
+    for (int n = 0; n < NT; ++n) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float v = activate(acc[n][r] + bias_v[n], g.relu);
-        if (obase) obase[orow * g.ldo + 32 * n] = v;
-        cs[n] += v;
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = 8 * h + r8;
+          const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;
+          const float v = activate(acc[n][r] + bias_v[n], g.relu);
+          stage[rl * 32 + li] = v;
+          if (wrow0 + 16 * h + rl < g.n_rows) cs[n] += v;
+        }
+        if (obase) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
+            if (wrow0 + 16 * h + 8 * i + srow < g.n_rows)
+              *reinterpret_cast<float4*>(obase + static_cast<int64_t>(16 * h + 8 * i) * g.ldo + 32 * n) = v;
+          }
+        }
+      }
+    }
+  } else {
+    float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + g.out_col0 + li : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < g.n_rows) {
+        const int64_t orow = g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float v = activate(acc[n][r] + bias_v[n], g.relu);
+          if (obase) obase[orow * g.ldo + 32 * n] = v;
+          cs[n] += v;
+        }
       }
     }
   }
-  if (g.colsum != nullptr) {
+  if (g.colsum != nullptr && wrow0 < g.n_rows) {
+    float* dst = g.colsum + (b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x * 4 + wave) * g.colsum_ld + g.out_col0 + li;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
+      if (lh == 0) dst[32 * n] = cs[n];
     }
-    __syncthreads();
-    if (tid < BN) {
-      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
+  }
+}
+
+// Weights-resident variant for 32 * NKT <= 256 total K: a workgroup of twelve waves copies the
+// whole weight matrix into LDS once, then its waves work on their own, with no barrier after the
+// first: every sample's 32-row groups are dealt out in runs of `gpw` consecutive groups, one run
+// per wave (`wps` waves per sample).  The A tile of step t+1 -- the next group's first tile at a
+// group's last step -- is requested before the MFMAs of step t, into the other of two register
+// buffers, so a wave always has one tile in flight behind its matrix work and the waves of a SIMD
+// drift apart instead of stalling together.  Rows past the end of a sample are clamped for the
+// loads and masked in the epilogue.  Column sums: one partial row per wave (its whole run).
+constexpr int kResWaves = 12;
+constexpr int kResThreads = 64 * kResWaves;
+constexpr size_t kResMaxLds = 160 * 1024;
+
+template <int NT, int NKT>
+__global__ __launch_bounds__(kResThreads) void k_gemm_resident(GemmArgs g, int groups_per_sample, int wps, int gpw,
+                                                               int batch) {
+  constexpr int BN = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) float res_smem[];
+  // Weight image: for K tile kt, 8-row chunk c and column tile n, one 1 KiB piece in lane order:
+  // lane (lh, li) finds rows 32kt + 8c + 4lh + 0..3 of column 32n + li as one float4.
+  float* Ws = res_smem;   // [NKT][4][NT][64][4]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int t0 = g.seg[0].k / kBK, t1 = g.n_seg > 1 ? g.seg[1].k / kBK : 0;   // K tiles of segments 0, 1
+
+  {
+    int kbase = 0;
+    for (int s = 0; s < g.n_seg; ++s) {
+      const GemmSeg& sg = g.seg[s];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float* w = sg.w[t];
+        for (int i = tid; i < sg.k * 8; i += kResThreads) {
+          const int row = kbase + (i >> 3), c4 = i & 7;
+          const float4 v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
+          // row = 8 * chunk + 4 * half + j
+          float* dst = Ws + (((row >> 3) * NT + t) * 64 + ((row >> 2) & 1) * 32 + 4 * c4) * 4 + (row & 3);
+          dst[0] = v.x;
+          dst[4] = v.y;
+          dst[8] = v.z;
+          dst[12] = v.w;
+        }
+      }
+      kbase += sg.k;
+    }
+  }
+  __syncthreads();
+
+  const int wid = blockIdx.x * kResWaves + wave;
+  const int b = wid / wps;
+  if (b >= batch) return;
+  const int slot = wid - b * wps;
+  int grp = slot * gpw;
+  const int grp_end = min(grp + gpw, groups_per_sample);
+
+  // this lane's (clamped) row of group grp_, counted over all samples
+  auto lane_row = [&](int grp_) {
+    int row = grp_ * kRowGroup + li;
+    row = row < g.n_rows ? row : g.n_rows - 1;
+    return static_cast<uint32_t>(b) * static_cast<uint32_t>(g.n_rows) + static_cast<uint32_t>(row);
+  };
+  // uniform base pointer + 32-bit per-lane byte offset (the host checks that every operand
+  // segment and the output are smaller than 4 GiB)
+  auto load_tile = [&](uint32_t arow, int kt, float4 (&a)[4]) {
+    const int s = kt < t0 ? 0 : (kt < t0 + t1 ? 1 : 2);
+    const int k0 = kBK * (kt - (s == 0 ? 0 : (s == 1 ? t0 : t0 + t1)));
+    const float* base = s == 0 ? g.seg[0].a : (s == 1 ? g.seg[1].a : g.seg[2].a);
+    const uint32_t lda = static_cast<uint32_t>(s == 0 ? g.seg[0].lda : (s == 1 ? g.seg[1].lda : g.seg[2].lda));
+    const char* sb = reinterpret_cast<const char*>(base + k0);
+    const uint32_t voff = (arow * lda + 4u * static_cast<uint32_t>(lh)) * 4u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const float4*>(sb + voff + 32u * c);
+  };
+
+  f32x16 acc[NT];
+  const float4* wl = reinterpret_cast<const float4*>(Ws) + lane;
+  auto multiply = [&](int kt, const float4 (&a)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4 w[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w[n] = wl[((kt * 4 + c) * NT + n) * 64];
+      // the NT accumulators take turns, so no MFMA waits for the one before it
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, w[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, w[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, w[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, w[n].w, acc[n], 0, 0, 0);
+    }
+  };
+  // Epilogue: bias, activation, column sums, and the tile's way to memory.  A lane holds one column
+  // of 16 rows; storing that directly would take 64 one-dword store instructions per group.  The
+  // wave instead passes 16 rows x 32 columns at a time through its own 2 KiB of LDS and picks them
+  // up row-wise, so a store instruction writes eight full 128-byte lines (four floats per lane).
+  const bool has_out = g.out != nullptr;
+  const uint32_t ldo = static_cast<uint32_t>(g.ldo);
+  float* stage = res_smem + 32 * NKT * BN + wave * (16 * 32);
+  const int srow = lane >> 3, scol = 4 * (lane & 7);
+  float bias_v[NT], cs[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + 32 * n + li] : 0.0f;
+    cs[n] = 0.0f;
+  }
+  auto epilogue = [&](auto full_tag, int row0) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    // this lane's first pick-up row as a 32-bit byte offset; the steps between rows are uniform
+    const uint32_t voff =
+        ((static_cast<uint32_t>(b) * static_cast<uint32_t>(g.out_rows) + static_cast<uint32_t>(row0 + srow)) * ldo +
+         static_cast<uint32_t>(g.out_col0 + scol)) * 4u;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = 8 * h + r8;
+          const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;   // row within this half of the tile
+          const float v = activate(acc[n][r] + bias_v[n], g.relu);
+          stage[rl * 32 + li] = v;
+          if (FULL || row0 + 16 * h + rl < g.n_rows) cs[n] += v;
+        }
+        if (has_out) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
+            char* orow = reinterpret_cast<char*>(g.out + static_cast<uint32_t>(16 * h + 8 * i) * ldo);
+            if (FULL || row0 + 16 * h + 8 * i + srow < g.n_rows)
+              *reinterpret_cast<float4*>(orow + voff + 128u * n) = v;
+          }
+        }
+      }
+    }
+  };
+
+  uint32_t cur = lane_row(grp);
+  float4 a0[4], a1[4];
+  load_tile(cur, 0, a0);
+  while (true) {
+    const bool has_next = grp + 1 < grp_end;
+    const uint32_t nxt = lane_row(has_next ? grp + 1 : grp);   // a finished wave re-reads its own rows: harmless
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt += 2) {
+      load_tile(cur, kt + 1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(kt, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < NKT)
+        load_tile(cur, kt + 2, a0);
+      else
+        load_tile(nxt, 0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(kt + 1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // Take delivery of the next group's first tile now, while only loads are outstanding: a wait
+    // placed after the stores below would have to cover them as well (loads and stores share one
+    // counter), and the wave would sit out its own write latency at the top of every group.
+    asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x), "+v"(a0[2].x), "+v"(a0[3].x));
+    const int row0 = grp * kRowGroup;
+    if (row0 + kRowGroup <= g.n_rows)
+      epilogue(std::true_type{}, row0);
+    else
+      epilogue(std::false_type{}, row0);
+    if (!has_next) break;
+    ++grp;
+    cur = nxt;
+  }
+  if (g.colsum != nullptr) {
+    float* dst = g.colsum + (static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + slot) * g.colsum_ld +
+                 g.out_col0 + li;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      cs[n] += __shfl_xor(cs[n], 32);
+      if (lh == 0) dst[32 * n] = cs[n];
     }
   }
 }
@@ -385,7 +601,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
   constexpr int kTileVec = SPL * 4 * BN;                  // uint4 per K tile of the weight image
   constexpr int kStage = (kTileVec + kThreads - 1) / kThreads;
   __shared__ uint4 Bs[2][kTileVec];
-  __shared__ float red[4 * BN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -504,16 +719,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
       }
     }
   }
-  if (g.colsum != nullptr) {
+  if (g.colsum != nullptr && row0 + 32 * wave < g.n_rows) {
+    float* dst = g.colsum + (b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x * 4 + wave) * g.colsum_ld + g.out_col0 + li;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
+      if (lh == 0) dst[32 * n] = cs[n];
     }
   }
 }
@@ -557,13 +768,98 @@ int launch_gemm_split(const GemmArgs& g, int nt, dim3 grid, uint4* wpack, hipStr
   return GUNET_OK;
 }
 
+// The weights-resident kernel takes launches whose operand segments are whole K tiles adding up to
+// 128 or 256, with 96 or 128 output columns and identity row mapping.
+inline size_t resident_lds_bytes(int nt, int nkt) {   // weights + 2 KiB of store staging per wave
+  return sizeof(float) * (static_cast<size_t>(32 * nkt) * 32 * nt + static_cast<size_t>(kResWaves) * 16 * 32);
+}
+
+inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
+  if (g.row_map != nullptr || (nt != 3 && nt != 4)) return false;
+  for (int s = 0; s < g.n_seg; ++s)
+    if (g.seg[s].k % kBK != 0) return false;
+  const int kt = gemm_ktiles(g);
+  if (kt != 4 && kt != 8) return false;
+  if (resident_lds_bytes(nt, kt) > kResMaxLds) return false;
+  for (int s = 0; s < g.n_seg; ++s)   // 32-bit byte offsets into every operand segment and the output
+    if (batch * g.n_rows * g.seg[s].lda * 4 >= (int64_t{1} << 32)) return false;
+  if (batch * (g.out_rows ? g.out_rows : g.n_rows) * g.ldo * 4 >= (int64_t{1} << 32)) return false;
+  return batch * ceil_div(g.n_rows, kRowGroup) < (1 << 30);
+}
+
+inline int device_cu_count() {
+  static int n_cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (n_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n_cus[dev] = n;
+  }
+  return n_cus[dev];
+}
+
+// Work split of the resident kernel: every sample's row groups in runs of gpw, wps waves per sample.
+struct ResidentSplit {
+  int groups, wps, gpw;
+};
+
+inline ResidentSplit resident_split(int n_rows, int64_t batch) {
+  ResidentSplit r;
+  r.groups = static_cast<int>(ceil_div(n_rows, kRowGroup));
+  const int64_t waves = static_cast<int64_t>(device_cu_count()) * kResWaves;
+  const int per_sample = static_cast<int>(std::max<int64_t>(1, waves / batch));
+  r.gpw = static_cast<int>(ceil_div(r.groups, std::min(per_sample, r.groups)));
+  r.wps = static_cast<int>(ceil_div(r.groups, r.gpw));
+  return r;
+}
+
+// Which kernel a launch gets: the split-bf16 one when such a mode is on and a weight-image
+// buffer is there, else the weights-resident one where it applies, else the tiled float32 one.
+inline bool takes_split(const void* wpack) { return mode_pieces(g_matmul_mode) > 0 && wpack != nullptr; }
+inline bool takes_resident(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
+  return !takes_split(wpack) && resident_ok(g, nt, batch);
+}
+
+// Rows of column-sum partials per sample that a launch writes (from colsum_tile0 on).
+inline int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
+  if (g.n_rows == 0) return 0;
+  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch).wps;
+  return static_cast<int>(ceil_div(g.n_rows, kRowGroup));
+}
+
+template <int NT, int NKT>
+int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
+  static bool raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
+  const size_t lds = resident_lds_bytes(NT, NKT);
+  int dev = 0;
+  GUNET_HIP_TRY(hipGetDevice(&dev));
+  GUNET_REQUIRE(dev >= 0 && dev < 64, "launch_gemm: device index %d", dev);
+  if (!raised[dev]) {
+    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResMaxLds)));
+    raised[dev] = true;
+  }
+  const ResidentSplit sp = resident_split(g.n_rows, batch);
+  const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kResWaves));
+  k_gemm_resident<NT, NKT><<<blocks, kResThreads, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw, static_cast<int>(batch));
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+int launch_gemm_resident(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
+  const int kt = gemm_ktiles(g);
+  if (nt == 4) return kt == 4 ? launch_resident_inst<4, 4>(g, batch, stream) : launch_resident_inst<4, 8>(g, batch, stream);
+  return kt == 4 ? launch_resident_inst<3, 4>(g, batch, stream) : launch_resident_inst<3, 8>(g, batch, stream);
+}
+
 // wpack: scratch of at least wpack_bytes(gemm_ktiles(g), nt) for the split modes (may be null in
 // GUNET_MATMUL_F32 mode).
 int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stream) {
   if (g.n_rows == 0 || batch == 0) return GUNET_OK;
   if (g.out_rows == 0) g.out_rows = g.n_rows;
   dim3 grid(static_cast<unsigned>(ceil_div(g.n_rows, kBM)), static_cast<unsigned>(batch));
-  if (g.colsum != nullptr && g.colsum_tiles == 0) g.colsum_tiles = static_cast<int>(grid.x);
+  if (g.colsum != nullptr && g.colsum_tiles == 0) g.colsum_tiles = gemm_colsum_rows(g, nt, batch, wpack);
   if (g.colsum_ld == 0) {
     g.colsum_ld = 32 * nt;
     if (g.colsum != nullptr && g.out_col0 != 0) {
@@ -572,13 +868,14 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
     }
   }
   ProfScope prof(kProfGemm, stream);
-  const int pieces = mode_pieces(g_matmul_mode);
-  if (pieces > 0 && wpack != nullptr) {
+  if (takes_split(wpack)) {
+    const int pieces = mode_pieces(g_matmul_mode);
     uint4* wp = static_cast<uint4*>(wpack);
     if (pieces == 3) return launch_gemm_split<3>(g, nt, grid, wp, stream);
     if (pieces == 2) return launch_gemm_split<2>(g, nt, grid, wp, stream);
     return launch_gemm_split<1>(g, nt, grid, wp, stream);
   }
+  if (resident_ok(g, nt, batch)) return launch_gemm_resident(g, nt, batch, stream);
   switch (nt) {
     case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(g); break;
     case 2: k_gemm_f32<2><<<grid, kThreads, 0, stream>>>(g); break;
@@ -1016,17 +1313,17 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const float4* src = reinterpret_cast<const float4*>(npart + b * n_nblk * static_cast<int64_t>(U)) + cq;
     int i = sub;
-    for (; i + S < n_nblk; i += 2 * S) {
-      const float4 a = src[static_cast<int64_t>(i) * QC];
-      const float4 c = src[static_cast<int64_t>(i + S) * QC];
-      s0 += static_cast<double>(a.x);
-      s1 += static_cast<double>(a.y);
-      s2 += static_cast<double>(a.z);
-      s3 += static_cast<double>(a.w);
-      s0 += static_cast<double>(c.x);
-      s1 += static_cast<double>(c.y);
-      s2 += static_cast<double>(c.z);
-      s3 += static_cast<double>(c.w);
+    for (; i + 7 * S < n_nblk; i += 8 * S) {   // eight partial rows in flight, added in order
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[static_cast<int64_t>(i + j * S) * QC];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s0 += static_cast<double>(v[j].x);
+        s1 += static_cast<double>(v[j].y);
+        s2 += static_cast<double>(v[j].z);
+        s3 += static_cast<double>(v[j].w);
+      }
     }
     for (; i < n_nblk; i += S) {
       const float4 a = src[static_cast<int64_t>(i) * QC];
@@ -1093,21 +1390,21 @@ struct LayerWorkspace {
   float* nbias;   // [U]
   float* ebias;   // [B, U]
   float* gbias;   // [B, U]
-  float* npart;   // [B, n_nblk + 5, U]
+  float* npart;   // [B, n_nblk + 5, U]   column sums per 32-row group
   float* epart;   // [B, 4, n_eblk, u]
   void* wpack;    // weight image of the GEMM in flight (split-bf16 matmul modes)
   int n_nblk, n_eblk;
   size_t bytes;
 };
 
-// One layout serves both entry points: the upsampling form needs at most 4 node tiles more than
-// the generic one (one partly filled tile per quadrant) and less of everything else.
+// One layout serves both entry points: the upsampling form needs at most 4 row groups more than
+// the generic one (one partly filled group per quadrant) and less of everything else.
 LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int units, void* base) {
   LayerWorkspace ws;
   const size_t n = static_cast<size_t>(g->n_nodes), bsz = static_cast<size_t>(batch), U = units, u = units / 4;
   int max_e = 0;
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
-  ws.n_nblk = static_cast<int>(ceil_div(g->n_nodes, kBM));
+  ws.n_nblk = static_cast<int>(ceil_div(g->n_nodes, kRowGroup));
   ws.n_eblk = static_cast<int>(ceil_div(max_e > 0 ? max_e : 1, kEdgesPerBlock));
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -1264,24 +1561,36 @@ int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const flo
                  : launch_edge_mlp_ut<2>(a, chunks, vec_ok && all_feat, grid, stream);
 }
 
-// GEMM with U output columns as U/128 launches of 128 columns.  `w_of(col)` gives the weight
-// pointer of the 32-column tile starting at output column `col` for segment s.
+// GEMM with U output columns as U/128 launches of 128 columns.  `w_of(s, col)` gives the weight
+// pointer of segment s for the 32-column tile starting at output column `col`.
 template <typename WeightOf>
-int launch_gemm_columns(GemmArgs g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
+GemmArgs columns_block(const GemmArgs& g, int units, int col0, const float* bias, int bias_stride, float* out,
+                       float* colsum, WeightOf w_of) {
+  GemmArgs gc = g;
+  for (int s = 0; s < g.n_seg; ++s)
+    for (int t = 0; t < 4; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
+  gc.bias = bias ? bias + col0 : nullptr;
+  gc.bias_stride = bias_stride;
+  gc.out = out;
+  gc.ldo = units;
+  gc.out_col0 = col0;
+  gc.colsum = colsum;
+  gc.colsum_ld = units;
+  return gc;
+}
+
+// Column-sum partial rows per sample such a GEMM writes (the same for each of its column blocks).
+inline int columns_colsum_rows(const GemmArgs& g, int units, int64_t batch, const void* wpack) {
+  GemmArgs gc = g;
+  gc.ldo = units;
+  return gemm_colsum_rows(gc, 4, batch, wpack);
+}
+
+template <typename WeightOf>
+int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
                         float* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
-  for (int col0 = 0; col0 < units; col0 += 128) {
-    GemmArgs gc = g;
-    for (int s = 0; s < g.n_seg; ++s)
-      for (int t = 0; t < 4; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
-    gc.bias = bias ? bias + col0 : nullptr;
-    gc.bias_stride = bias_stride;
-    gc.out = out;
-    gc.ldo = units;
-    gc.out_col0 = col0;
-    gc.colsum = colsum;
-    gc.colsum_ld = units;
-    GUNET_TRY(launch_gemm(gc, 4, batch, wpack, stream));
-  }
+  for (int col0 = 0; col0 < units; col0 += 128)
+    GUNET_TRY(launch_gemm(columns_block(g, units, col0, bias, bias_stride, out, colsum, w_of), 4, batch, wpack, stream));
   return GUNET_OK;
 }
 
@@ -1481,6 +1790,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_LAUNCH_CHECK();
   }
 
+  int n_partials = 0;   // column-sum partial rows per sample
   {  // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
     GemmArgs g = {};
     int s = 0;
@@ -1504,10 +1814,12 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     g.n_rows = n;
     g.relu = relu;
     auto w_of = [&](int seg, int col) { return w->node_w + row_of[seg] * U + col; };
+    n_partials = columns_colsum_rows(g, U, batch, ws.wpack);
+    g.colsum_tiles = n_partials;
     GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
   }
 
-  return launch_global_update(p, ut, global_in, n > 0 ? ws.n_nblk : 0, relu, batch, ws, global_out, stream);
+  return launch_global_update(p, ut, global_in, n_partials, relu, batch, ws, global_out, stream);
 }
 
 int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w,
@@ -1575,30 +1887,18 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
   // (the rows themselves are dropped by the caller, hybrid_gnn.py:377).  Fine rows: x is zero and
   // the aggregate is the single incoming message in the columns of its quadrant, so each
   // quadrant's edges are one K=u GEMM scattered to the fine rows.
-  const int tiles_c = static_cast<int>(ceil_div(n_coarse, kBM));
-  int tiles_total = tiles_c;
-  int tile0[4];
+  GemmArgs gc = {};
+  gc.n_seg = 1;
+  gc.seg[0].a = x;
+  gc.seg[0].lda = w->c_in;
+  gc.seg[0].k = w->c_in;
+  gc.seg[0].ldw = U;
+  gc.n_rows = n_coarse;
+  gc.relu = relu;
+  GemmArgs gq[4] = {};
+  int tiles_total = columns_colsum_rows(gc, U, batch, ws.wpack);
   for (int q = 0; q < 4; ++q) {
-    tile0[q] = tiles_total;
-    tiles_total += static_cast<int>(ceil_div(graph->n_edges[q], kBM));
-  }
-  if (n_coarse > 0) {
-    GemmArgs g = {};
-    g.n_seg = 1;
-    g.seg[0].a = x;
-    g.seg[0].lda = w->c_in;
-    g.seg[0].k = w->c_in;
-    g.seg[0].ldw = U;
-    g.n_rows = n_coarse;
-    g.colsum_tiles = tiles_total;
-    g.colsum_tile0 = 0;
-    g.relu = relu;
-    auto w_of = [&](int, int col) { return w->node_w + col; };
-    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, nullptr, ws.npart, w_of, ws.wpack, stream));
-  }
-  for (int q = 0; q < 4; ++q) {
-    if (graph->n_edges[q] == 0) continue;
-    GemmArgs g = {};
+    GemmArgs& g = gq[q];
     g.n_seg = 1;
     g.seg[0].a = msg[q];
     g.seg[0].lda = u;
@@ -1609,11 +1909,22 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     g.row_map = graph->edge_index[q] + 1;   // receiver column of the edge list
     g.row_map_stride = 2;
     g.row_map_sub = n_coarse;
-    g.colsum_tiles = tiles_total;
-    g.colsum_tile0 = tile0[q];
     g.relu = relu;
+    g.colsum_tile0 = tiles_total;
+    tiles_total += columns_colsum_rows(g, U, batch, ws.wpack);
+  }
+  GUNET_REQUIRE(tiles_total <= ws.n_nblk + 5, "gn_upsample: %d column-sum rows for a buffer of %d", tiles_total,
+                ws.n_nblk + 5);
+  if (n_coarse > 0) {
+    gc.colsum_tiles = tiles_total;
+    auto w_of = [&](int, int col) { return w->node_w + col; };
+    GUNET_TRY(launch_gemm_columns(gc, U, batch, ws.gbias, U, nullptr, ws.npart, w_of, ws.wpack, stream));
+  }
+  for (int q = 0; q < 4; ++q) {
+    if (graph->n_edges[q] == 0) continue;
+    gq[q].colsum_tiles = tiles_total;
     auto w_of = [&](int, int col) { return w->node_w + static_cast<int64_t>(w->c_in + u * q) * U + col; };
-    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
+    GUNET_TRY(launch_gemm_columns(gq[q], U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
   }
   return launch_global_update(p, ut, global_in, tiles_total, relu, batch, ws, global_out, stream);
 }
