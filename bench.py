@@ -34,6 +34,8 @@ def parse_args():
     ap.add_argument('--width', type=int, default=436)
     ap.add_argument('--density', type=float, default=0.45)
     ap.add_argument('--dense', action='store_true', help='all pixels are nodes (MFMA stress graph)')
+    ap.add_argument('--min-units', type=int, default=128, choices=[128, 256],
+                    help='width of every block (128 = the shipped checkpoint; 256 = the wide stress variant)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-runs', type=int, default=3)
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel event pass')
@@ -96,9 +98,9 @@ def main():
     else:
         node_loc, edge_index, direction = synthetic.road_graph(args.height, args.width, args.density, 0)
     n_nodes = node_loc.shape[0]
-    weights = synthetic.random_weights(synthetic.graph_unet_shapes(), 1)
+    weights = synthetic.random_weights(synthetic.graph_unet_shapes_for(32, min_units=args.min_units), 1)
     model = gunet_amd.GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
-                                use_bias=True, use_global=True, output_activation=None)
+                                use_bias=True, use_global=True, output_activation=None, min_units=args.min_units)
     model.load_weights(weights, dev)
 
     torch.cuda.synchronize()
@@ -218,7 +220,7 @@ def main():
         loc, edges = pp.pooled_loc, pp.edge_index
         n_levels.append(pp.n_pooled)
         e_levels.append(sum(pp.n_pooled_edges))
-    work = workload.work_per_sample(workload.layer_table(n_levels, e_levels))
+    work = workload.work_per_sample(workload.layer_table(n_levels, e_levels, units=args.min_units))
     result = {
         'metric': 'GraphUNet fwd samples/sec (495x436 grid)', 'value': samples_per_s, 'unit': 'samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -227,7 +229,7 @@ def main():
                   'split2': 'f32 storage, 2xbf16-split matmul', 'bf16': 'bf16 matmul, f32 storage/accumulate'}[args.matmul],
         'data': 'synthetic',
         'config': {
-            'workload': ('full GraphUNet fwd, checkpoint shapes (12x8-ch in, 12x8-ch out, width 128, depth 3), '
+            'workload': (f'full GraphUNet fwd, checkpoint shapes (12x8-ch in, 12x8-ch out, width {args.min_units}, depth 3), '
                          f'one {args.height}x{args.width} ' + ('dense grid' if args.dense else f'road graph (density {args.density}, seed 0)')
                          + f', batch {B} per GPU'),
             'nodes_per_level': n_levels, 'quadrant_edges_per_level': e_levels, 'batch_per_gpu': B,

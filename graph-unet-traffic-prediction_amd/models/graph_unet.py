@@ -10,10 +10,15 @@ class GraphUNet:
     depth x (graph upsample + skip concat + 2 GN layers) -> Dense out (no bias).
 
     call(x, graph) takes x [N, F] (or [B, N, F]) and the graph dict and returns
-    (y [N, out_units], graph), as the reference does."""
+    (y [N, out_units], graph), as the reference does.
+
+    The reference floors every block width at 128 and builds both bottleneck layers 128 wide
+    (models/graph_unet.py:37,40,46-49,53); `min_units` (keyword-only, not in the reference) replaces
+    that 128, so GraphUNet(64, min_units=256) is 256 wide throughout.  Block widths of 128 and 256
+    are implemented."""
 
     def __init__(self, units, out_units=8, depth=5, activation=None, layer_type=None, use_bias=False,
-                 use_global=False, output_activation=None, **layer_args):
+                 use_global=False, output_activation=None, *, min_units=128, **layer_args):
         self.depth = depth
         self.downsampling_layers = []
         self.upsampling_layers = []
@@ -23,19 +28,19 @@ class GraphUNet:
         self.use_bias = use_bias
         layer_units = units
         GraphLayer = L.get(layer_type)
-        self.in_layer = Dense(max(layer_units, 128))
+        self.in_layer = Dense(max(layer_units, min_units))
         for i in range(self.depth):
-            ds = GraphDownsamplingBlock(max(layer_units, 128), activation=activation, use_bias=use_bias,
+            ds = GraphDownsamplingBlock(max(layer_units, min_units), activation=activation, use_bias=use_bias,
                                         diffuse_graph=False, layer_type=layer_type, use_global=use_global)
             layer_units = units * 2 ** (i + 1)
             self.downsampling_layers.append(ds)
-        self.bottleneck_gcn_1 = GraphLayer(128, activation=self.activation, use_bias=self.use_bias,
+        self.bottleneck_gcn_1 = GraphLayer(min_units, activation=self.activation, use_bias=self.use_bias,
                                            learn_global_scale=self.use_global, use_global=self.use_global)
-        self.bottleneck_gcn_2 = GraphLayer(128, activation=self.activation, use_bias=self.use_bias,
+        self.bottleneck_gcn_2 = GraphLayer(min_units, activation=self.activation, use_bias=self.use_bias,
                                            learn_global_scale=self.use_global, use_global=self.use_global)
         for i in range(self.depth):
             layer_units = units * 2 ** (self.depth - i - 1)
-            us = GraphUpsamplingBlock(max(layer_units, 128), activation=activation, use_bias=use_bias,
+            us = GraphUpsamplingBlock(max(layer_units, min_units), activation=activation, use_bias=use_bias,
                                       diffuse_graph=False, layer_type=layer_type, use_global=use_global,
                                       last_block=i == (self.depth - 1))
             self.upsampling_layers.append(us)

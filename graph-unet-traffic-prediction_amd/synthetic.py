@@ -91,20 +91,21 @@ def graph_unet_shapes(units=128, in_features=104, out_units=96, depth=3, f_e0=16
     return shapes
 
 
-def graph_unet_block_units(units, depth=3):
+def graph_unet_block_units(units, depth=3, min_units=128):
     """Widths the constructor gives the blocks (models/graph_unet.py:37-55): in_layer and the
     down blocks max(units * 2**i, 128), both bottleneck layers 128, the up blocks
-    max(units * 2**(depth - i - 1), 128)."""
-    down = [max(units * 2 ** i, 128) for i in range(depth)]
-    up = [max(units * 2 ** (depth - i - 1), 128) for i in range(depth)]
-    return max(units, 128), down, 128, up
+    max(units * 2**(depth - i - 1), 128).  min_units replaces the 128 (a uniform-width variant,
+    e.g. units=64, min_units=256, that the reference constructor itself cannot build)."""
+    down = [max(units * 2 ** i, min_units) for i in range(depth)]
+    up = [max(units * 2 ** (depth - i - 1), min_units) for i in range(depth)]
+    return max(units, min_units), down, min_units, up
 
 
-def graph_unet_shapes_for(units, in_features=104, out_units=96, depth=3, f_e0=16, g0=113):
+def graph_unet_shapes_for(units, in_features=104, out_units=96, depth=3, f_e0=16, g0=113, min_units=128):
     """Variable name -> shape of GraphUNet(units, depth=depth) for any constructor `units`,
     following the widths through models/graph_unet.py:60-84 (units <= 32 gives the shipped
     checkpoint's uniform 128)."""
-    w_in, down, w_mid, up = graph_unet_block_units(units, depth)
+    w_in, down, w_mid, up = graph_unet_block_units(units, depth, min_units)
     shapes = {'in_layer/kernel': (in_features, w_in), 'in_layer/bias': (w_in,)}
     c, f_e, g = w_in, f_e0, g0
     skip_c, skip_fe, skip_g = [], [], []

@@ -2,7 +2,7 @@
 level sizes.  These are the figures the benchmark's roofline fractions are computed from.
 
 Per GeoQuadrantGCN layer on N nodes, E = sum of the four quadrant edge counts, input width C,
-edge-feature width F, global width G, U = 128 units, u = U / 4 (float32 = 4 bytes):
+edge-feature width F, global width G, U units (128 or 256), u = U / 4 (float32 = 4 bytes):
   GEMM FLOPs      2*N*C*U (4 node embeddings)  +  2*N*(C + U + G)*U (node MLP, as the reference
                   writes it: the tiled global columns are counted although the kernels fold them
                   into a per-sample bias)
@@ -16,13 +16,11 @@ the MFMA kernels use these, so they can never exceed 1, and the as-written total
 beside them.
 """
 
-U = 128
-SMALL_U = U // 4
-
-
-def layer_table(n_nodes, n_edges, f_e0=16, g0=113, in_features=104, out_units=96):
+def layer_table(n_nodes, n_edges, f_e0=16, g0=113, in_features=104, out_units=96, units=128):
     """n_nodes[l], n_edges[l] (sum over quadrants) for levels 0..depth -> list of layer dicts in
-    execution order (GN layers and the two dense layers)."""
+    execution order (GN layers and the two dense layers) of a U-Net that is `units` wide
+    throughout (128 = the shipped checkpoint)."""
+    U, SMALL_U = units, units // 4
     depth = len(n_nodes) - 1
     rows = [dict(name='in_layer', kind='dense', n=n_nodes[0], k=in_features, out=U)]
     f_e, g = f_e0, g0
@@ -43,6 +41,8 @@ def layer_table(n_nodes, n_edges, f_e0=16, g0=113, in_features=104, out_units=96
         rows.append(dict(name=f'up{d}.gcn0', kind='gn', n=n_nodes[lvl], e=n_edges[lvl], c=2 * U, f=skip_fe[lvl], g=U))
         rows.append(dict(name=f'up{d}.gcn1', kind='gn', n=n_nodes[lvl], e=n_edges[lvl], c=U, f=SMALL_U, g=U))
     rows.append(dict(name='out_model', kind='dense', n=n_nodes[0], k=U, out=out_units))
+    for r in rows:
+        r['U'] = U
     return rows
 
 
@@ -52,6 +52,7 @@ def work_per_sample(rows):
              pool_bytes=0.0, gemm_launches=0, edge_launches=0, aggregate_launches=0,
              gemm_flops_executed=0.0, edge_flops_executed=0.0, aggregate_bytes_executed=0.0)
     for r in rows:
+        U, SMALL_U = r['U'], r['U'] // 4
         if r['kind'] == 'dense':
             w['gemm_flops'] += 2.0 * r['n'] * r['k'] * r['out']
             w['gemm_flops_executed'] += 2.0 * r['n'] * r['k'] * r['out']

@@ -98,6 +98,19 @@ def test_graph_unet_wide(amd, oracle, units, depth):
         assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
 
 
+def test_graph_unet_uniform_256(amd, oracle):
+    """GraphUNet(64, min_units=256): every block 256 wide (the wide stress configuration)."""
+    x, graph, _ = make_case(oracle, 36, 44, 1.0, dense=True)
+    W = oracle.make_weights(oracle.graph_unet_shapes_for(64, min_units=256), 9)
+    assert W['bottleneck_gcn_1/node_transform/kernel'].shape == (256 + 256 + 256, 256)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    model = amd.GraphUNet(64, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                          use_bias=True, use_global=True, min_units=256).load_weights(W, 'cuda')
+    got_y, got_g = model(to_dev(x), graph_to_dev(graph))
+    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+
+
 def test_unsupported_width(amd):
     layer = amd.hybrid_gnn.GeoQuadrantGCN(512, activation='relu', use_bias=False, use_global=True)
     x = torch.zeros((4, 128), device='cuda')
