@@ -44,6 +44,31 @@ def parse_args():
     return ap.parse_args()
 
 
+GEMM_CLASSES = ('gemm_tiled', 'gemm_resident_k128', 'gemm_resident_k256', 'gemm_split')
+MFMA_CLASSES = GEMM_CLASSES + ('edge_mlp',)
+KERNEL_OF_CLASS = {'gemm_tiled': 'k_gemm_f32', 'gemm_resident_k128': 'k_gemm_resident<*, 4>',
+                   'gemm_resident_k256': 'k_gemm_resident<*, 8>', 'gemm_split': 'k_gemm_split', 'edge_mlp': 'k_edge_mlp',
+                   'aggregate': 'k_aggregate', 'segment_reduce': 'k_segment_reduce', 'layer_prologue': 'k_layer_prologue',
+                   'global_update': 'k_global_update', 'gather_rows': 'k_gather_rows', 'dense_naive': 'k_dense_naive'}
+
+
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
+    command (profiles/hbm_traffic_per_launch.json: FETCH_SIZE doubled as gfx950 needs, plus
+    WRITE_SIZE); None for a workload other than the default one or a kernel without an entry."""
+    default = (args.height, args.width, args.density, args.dense, args.min_units, args.batch, args.matmul) == \
+              (495, 436, 0.45, False, 128, 8, 'f32')
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic_per_launch.json')
+    if not default or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    entry = table.get('kernels', {}).get(kernel)
+    if entry is None:
+        return None
+    return {'bytes_per_launch': entry['hbm_MB_per_launch'] * 1e6, 'source': table.get('source', path)}
+
+
 def cpu_baseline(args, graph_np, weights, inputs_np):
     """Time the CPU restatement (oracle/, numpy) of the same forward on one sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -241,33 +266,43 @@ def main():
     }
     if prof is not None:
         steps = args.steps
-        per_class = {k: {'ms_per_step': v[0] / steps, 'launches_per_step': v[1] / steps} for k, v in prof.items() if v[1]}
-        result['kernels'] = per_class
-        gemm_ms, gemm_n = prof['gemm_f32']
-        edge_ms, edge_n = prof['edge_mlp']
-        agg_ms, agg_n = prof['aggregate']
-        # dominant kernel = the class with the most device time; MFMA classes are priced with the
-        # FLOPs they execute (as-written FLOPs of the reference are reported beside them)
-        dom = max(('gemm_f32', 'edge_mlp', 'aggregate'), key=lambda k: prof[k][0])
-        if dom == 'aggregate':
-            achieved = B * work['aggregate_bytes_executed'] * steps / (agg_ms * 1e-3) / 1e9
-            result['roofline'] = {'kernel': 'k_aggregate', 'bound': 'hbm', 'achieved': achieved,
-                                  'peak': workload.PEAK_HBM_GBPS, 'unit': 'GB/s',
-                                  'frac': achieved / workload.PEAK_HBM_GBPS, 'traffic': None,
-                                  'avg_launch_ms': agg_ms / agg_n}
+        result['kernels'] = {k: {'ms_per_step': v[0] / steps, 'launches_per_step': v[1] / steps,
+                                 ('gflop_per_step' if k in MFMA_CLASSES else 'MB_per_step'):
+                                     v[2] / steps / (1e9 if k in MFMA_CLASSES else 1e6)}
+                             for k, v in prof.items() if v[1]}
+        # dominant kernel = the class (one kernel template each) with the most device time; its work
+        # is what the library counted for exactly those launches
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, n, work_done = prof[dom]
+        products = {'f32': 1, 'split3': 6, 'split2': 3, 'bf16': 1}[args.matmul] if dom == 'gemm_split' else 1
+        if dom in MFMA_CLASSES:
+            peak = workload.PEAK_BF16_MFMA_TFLOPS if dom == 'gemm_split' else workload.PEAK_F32_MFMA_TFLOPS
+            achieved = products * work_done / (ms * 1e-3) / 1e12
+            roof = {'kernel': KERNEL_OF_CLASS[dom], 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
+                    'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None, 'avg_launch_ms': ms / n,
+                    'gflop_per_launch': work_done / n / 1e9}
+            if products > 1:
+                roof['note'] = f'{products} bf16 MFMA products per float32-class multiply-add; peak = dense bf16'
         else:
-            key = 'gemm' if dom == 'gemm_f32' else 'edge'
-            ms, n = (gemm_ms, gemm_n) if dom == 'gemm_f32' else (edge_ms, edge_n)
-            executed = B * work[key + '_flops_executed'] * steps
-            written = B * work[key + '_flops'] * steps
-            achieved = executed / (ms * 1e-3) / 1e12
-            result['roofline'] = {'kernel': 'k_gemm_f32' if dom == 'gemm_f32' else 'k_edge_mlp', 'bound': 'mfma',
-                                  'achieved': achieved, 'peak': workload.PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                  'frac': achieved / workload.PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                                  'avg_launch_ms': ms / n, 'executed_gflop_per_launch': executed / n / 1e9,
-                                  'as_written_tflops': written / (ms * 1e-3) / 1e12}
+            achieved = work_done / (ms * 1e-3) / 1e9
+            roof = {'kernel': KERNEL_OF_CLASS[dom], 'bound': 'hbm', 'achieved': achieved, 'peak': workload.PEAK_HBM_GBPS,
+                    'unit': 'GB/s', 'frac': achieved / workload.PEAK_HBM_GBPS, 'traffic': None,
+                    'avg_launch_ms': ms / n, 'MB_per_launch': work_done / n / 1e6}
+        traffic = measured_traffic(KERNEL_OF_CLASS[dom], args)
+        if traffic is not None:
+            roof['traffic'] = traffic['bytes_per_launch']
+            roof['traffic_source'] = traffic['source']
+        result['roofline'] = roof
+        gemm_ms = sum(prof[k][0] for k in GEMM_CLASSES)
+        gemm_flops = sum(prof[k][2] for k in GEMM_CLASSES)
+        edge_ms, edge_n, edge_flops = prof['edge_mlp']
+        agg_ms, agg_n, agg_bytes = prof['aggregate']
+        if gemm_ms > 0:
+            result['gemm_all'] = {'ms_per_step': gemm_ms / steps, 'launches_per_step': sum(prof[k][1] for k in GEMM_CLASSES) / steps,
+                                  'executed_tflops': gemm_flops / (gemm_ms * 1e-3) / 1e12,
+                                  'as_written_tflops': B * work['gemm_flops'] * steps / (gemm_ms * 1e-3) / 1e12}
         if agg_n:
-            agg_gbps = B * work['aggregate_bytes_executed'] * steps / (agg_ms * 1e-3) / 1e9
+            agg_gbps = agg_bytes / (agg_ms * 1e-3) / 1e9
             gs_gbps = B * (work['aggregate_bytes'] + work['gather_bytes']) * steps / ((agg_ms + edge_ms) * 1e-3) / 1e9
             result['gather_scatter'] = {
                 'aggregate_GBps': agg_gbps, 'aggregate_frac_of_hbm_peak': agg_gbps / workload.PEAK_HBM_GBPS,
@@ -277,7 +312,7 @@ def main():
                         'edge-MLP kernel) + segment-sum bytes of all 14 layers over edge-MLP + aggregate time'}
         mfma_ms = gemm_ms + edge_ms
         if mfma_ms > 0:
-            tf = B * work['total_flops_executed'] * steps / (mfma_ms * 1e-3) / 1e12
+            tf = (gemm_flops + edge_flops) / (mfma_ms * 1e-3) / 1e12
             result['mfma_utilisation'] = {'executed_tflops_over_gemm_and_edge_kernels': tf,
                                           'frac_of_f32_peak': tf / workload.PEAK_F32_MFMA_TFLOPS,
                                           'as_written_tflops': B * work['total_flops'] * steps / (mfma_ms * 1e-3) / 1e12}

@@ -48,7 +48,7 @@ class GnWeightsStruct(C.Structure):
 
 VoidP4 = C.c_void_p * 4
 I64x4 = C.c_int64 * 4
-PROF_CLASSES = 8
+PROF_CLASSES = 11
 F64xP = C.c_double * PROF_CLASSES
 I64xP = C.c_int64 * PROF_CLASSES
 
@@ -92,7 +92,7 @@ SIGNATURES = {
                                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     'gunet_profile_enable': (C.c_int, [C.c_int]),
-    'gunet_profile_collect': (C.c_int, [C.POINTER(F64xP), C.POINTER(I64xP)]),
+    'gunet_profile_collect': (C.c_int, [C.POINTER(F64xP), C.POINTER(I64xP), C.POINTER(F64xP)]),
     'gunet_profile_class_name': (C.c_char_p, [C.c_int]),
 }
 
@@ -148,10 +148,12 @@ def profile_enable(on):
 
 
 def profile_collect():
-    """{class name: (milliseconds, launches)} since the previous collect."""
-    ms, n = F64xP(), I64xP()
-    call('gunet_profile_collect', C.byref(ms), C.byref(n))
-    return {lib.gunet_profile_class_name(c).decode(): (float(ms[c]), int(n[c])) for c in range(PROF_CLASSES)}
+    """{class name: (milliseconds, launches, algorithmic work)} since the previous collect; work is
+    FLOPs for the matrix classes and bytes for aggregate / segment_reduce."""
+    ms, n, work = F64xP(), I64xP(), F64xP()
+    call('gunet_profile_collect', C.byref(ms), C.byref(n), C.byref(work))
+    return {lib.gunet_profile_class_name(c).decode(): (float(ms[c]), int(n[c]), float(work[c]))
+            for c in range(PROF_CLASSES)}
 
 
 def set_matmul_mode(mode):

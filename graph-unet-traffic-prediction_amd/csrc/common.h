@@ -69,7 +69,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Kernel classes of the optional event profiler (gunet_profile_*).
 enum ProfClass {
-  kProfGemm = 0,
+  kProfGemmTiled = 0,
   kProfEdgeMlp,
   kProfAggregate,
   kProfPrologue,
@@ -77,14 +77,19 @@ enum ProfClass {
   kProfSegment,
   kProfGather,
   kProfDenseNaive,
+  kProfGemmRes128,
+  kProfGemmRes256,
+  kProfGemmSplit,
   kProfCount
 };
 static_assert(kProfCount == GUNET_PROF_CLASSES, "profiler class table out of step with the header");
 
 // Brackets the launches issued during its lifetime with two events when profiling is enabled.
+// `work` is the algorithmic work of those launches: FLOPs for the matrix kernels, bytes for the
+// gather / scatter / reduce kernels.
 class ProfScope {
  public:
-  ProfScope(int cls, hipStream_t stream);
+  ProfScope(int cls, hipStream_t stream, double work = 0.0);
   ~ProfScope();
   ProfScope(const ProfScope&) = delete;
   ProfScope& operator=(const ProfScope&) = delete;
@@ -92,6 +97,7 @@ class ProfScope {
  private:
   int cls_;
   hipStream_t stream_;
+  double work_;
   void* start_ = nullptr;
   void* stop_ = nullptr;
 };

@@ -100,7 +100,8 @@ int launch_segment_reduce(const float* src, int64_t n_src, int32_t width, const 
                    (reinterpret_cast<uintptr_t>(out) % 16 == 0);
   const int64_t work = n_segments * (vec ? width / 4 : width);
   dim3 grid(static_cast<unsigned>(ceil_div(work, kThreads)), static_cast<unsigned>(batch));
-  ProfScope prof(kProfSegment, stream);
+  ProfScope prof(kProfSegment, stream,
+                 static_cast<double>(batch) * (4.0 * width * (n_src + n_segments) + 4.0 * (n_src + n_segments)));
   if (vec)
     k_segment_reduce<4, IS_MAX><<<grid, kThreads, 0, stream>>>(src, n_src, width, rowptr, perm,
                                                                n_segments, scale, out);
@@ -867,15 +868,19 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
       return GUNET_ERR_INVALID;
     }
   }
-  ProfScope prof(kProfGemm, stream);
-  if (takes_split(wpack)) {
+  const bool split = takes_split(wpack), resident = !split && resident_ok(g, nt, batch);
+  double flops = 0.0;
+  for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
+  ProfScope prof(split ? kProfGemmSplit : (!resident ? kProfGemmTiled : (gemm_ktiles(g) == 4 ? kProfGemmRes128 : kProfGemmRes256)),
+                 stream, flops);
+  if (split) {
     const int pieces = mode_pieces(g_matmul_mode);
     uint4* wp = static_cast<uint4*>(wpack);
     if (pieces == 3) return launch_gemm_split<3>(g, nt, grid, wp, stream);
     if (pieces == 2) return launch_gemm_split<2>(g, nt, grid, wp, stream);
     return launch_gemm_split<1>(g, nt, grid, wp, stream);
   }
-  if (resident_ok(g, nt, batch)) return launch_gemm_resident(g, nt, batch, stream);
+  if (resident) return launch_gemm_resident(g, nt, batch, stream);
   switch (nt) {
     case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(g); break;
     case 2: k_gemm_f32<2><<<grid, kThreads, 0, stream>>>(g); break;
@@ -1551,8 +1556,12 @@ int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const flo
   }
   // a direction whose features are absent reads nothing; the vector loader needs all of them
   dim3 grid(static_cast<unsigned>(n_eblk), 4, static_cast<unsigned>(batch));
-  ProfScope prof(kProfEdgeMlp, stream);
   const int chunks = (!any_feat || a.f_e == 0) ? 0 : (a.f_e + 7) / 8;
+  double edges_total = 0.0;
+  for (int q = 0; q < 4; ++q) edges_total += graph->n_edges[q];
+  const double u = 32.0 * ut;
+  ProfScope prof(kProfEdgeMlp, stream,
+                 2.0 * batch * edges_total * ((chunks ? a.f_e : 0) + (a.sender_only ? 1 : 2) * u) * u);
   if (a.sender_only && chunks != 0) {
     set_error("edge_mlp: the sender-only form takes no edge features");
     return GUNET_ERR_INVALID;
@@ -1782,7 +1791,9 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     a.scale = 1.0f / (3 + 1);
     a.agg = ws.agg;
     dim3 grid(static_cast<unsigned>(ceil_div(n, kThreads / (32 * ut))), static_cast<unsigned>(batch));
-    ProfScope prof(kProfAggregate, stream);
+    double edges_total = 0.0;
+    for (int q = 0; q < 4; ++q) edges_total += graph->n_edges[q];
+    ProfScope prof(kProfAggregate, stream, 4.0 * batch * (edges_total * u + edges_total + static_cast<double>(n) * U));
     if (ut == 1)
       k_aggregate<1><<<grid, kThreads, 0, stream>>>(a);
     else

@@ -11,6 +11,7 @@ namespace {
 
 struct Bracket {
   int cls;
+  double work;
   hipEvent_t start, stop;
 };
 
@@ -19,8 +20,9 @@ bool g_enabled = false;
 std::vector<Bracket> g_open;           // recorded, not yet collected
 std::vector<hipEvent_t> g_free_events; // reusable events
 
-const char* const kNames[kProfCount] = {"gemm_f32",      "edge_mlp",       "aggregate",  "layer_prologue",
-                                        "global_update", "segment_reduce", "gather_rows", "dense_naive"};
+const char* const kNames[kProfCount] = {"gemm_tiled",    "edge_mlp",       "aggregate",   "layer_prologue",
+                                        "global_update", "segment_reduce", "gather_rows", "dense_naive",
+                                        "gemm_resident_k128", "gemm_resident_k256", "gemm_split"};
 
 hipEvent_t take_event() {
   if (!g_free_events.empty()) {
@@ -35,7 +37,7 @@ hipEvent_t take_event() {
 
 }  // namespace
 
-ProfScope::ProfScope(int cls, hipStream_t stream) : cls_(cls), stream_(stream) {
+ProfScope::ProfScope(int cls, hipStream_t stream, double work) : cls_(cls), stream_(stream), work_(work) {
   std::lock_guard<std::mutex> lock(g_mu);
   if (!g_enabled) return;
   start_ = take_event();
@@ -51,7 +53,7 @@ ProfScope::~ProfScope() {
   if (start_ == nullptr) return;
   (void)hipEventRecord(static_cast<hipEvent_t>(stop_), stream_);
   std::lock_guard<std::mutex> lock(g_mu);
-  g_open.push_back({cls_, static_cast<hipEvent_t>(start_), static_cast<hipEvent_t>(stop_)});
+  g_open.push_back({cls_, work_, static_cast<hipEvent_t>(start_), static_cast<hipEvent_t>(stop_)});
 }
 
 }  // namespace gunet
@@ -66,8 +68,10 @@ int gunet_profile_enable(int on) {
   return GUNET_OK;
 }
 
-int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_host[GUNET_PROF_CLASSES]) {
-  GUNET_REQUIRE(ms_host != nullptr && launches_host != nullptr, "profile_collect: null output");
+int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_host[GUNET_PROF_CLASSES],
+                          double work_host[GUNET_PROF_CLASSES]) {
+  GUNET_REQUIRE(ms_host != nullptr && launches_host != nullptr && work_host != nullptr,
+                "profile_collect: null output");
   std::vector<Bracket> open;
   {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -76,6 +80,7 @@ int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_h
   for (int c = 0; c < GUNET_PROF_CLASSES; ++c) {
     ms_host[c] = 0.0;
     launches_host[c] = 0;
+    work_host[c] = 0.0;
   }
   int rc = GUNET_OK;
   for (const Bracket& b : open) {
@@ -88,6 +93,7 @@ int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_h
     } else if (b.cls >= 0 && b.cls < GUNET_PROF_CLASSES) {
       ms_host[b.cls] += ms;
       launches_host[b.cls] += 1;
+      work_host[b.cls] += b.work;
     }
   }
   std::lock_guard<std::mutex> lock(g_mu);

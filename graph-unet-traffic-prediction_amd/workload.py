@@ -87,4 +87,5 @@ def work_per_sample(rows):
 
 # Peaks used for the roofline fractions (dense, MI355X): float32 matrix cores and HBM3E.
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0

@@ -211,12 +211,18 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
 
 /* Per-kernel-class device timing.  While enabled, every kernel launch of the feature functions
  * is bracketed by two hipEvents on its stream; gunet_profile_collect() waits for them and
- * returns the summed milliseconds and the launch count per class since the previous collect.
- * Classes: 0 gemm_f32, 1 edge_mlp, 2 aggregate, 3 layer_prologue, 4 global_update,
- * 5 segment_reduce, 6 gather_rows, 7 dense_naive. */
-#define GUNET_PROF_CLASSES 8
+ * returns, per class and since the previous collect, the summed milliseconds, the launch count
+ * and the algorithmic work of those launches: FLOPs (2 per multiply-add of the products the
+ * caller asked for, without tile padding) for the matrix classes, bytes (each operand read once,
+ * each result written once) for aggregate and segment_reduce, 0 for the rest.
+ * Classes: 0 gemm_tiled (k_gemm_f32), 1 edge_mlp, 2 aggregate, 3 layer_prologue,
+ * 4 global_update, 5 segment_reduce, 6 gather_rows, 7 dense_naive, 8 gemm_resident_k128
+ * (k_gemm_resident<*, 4>), 9 gemm_resident_k256 (k_gemm_resident<*, 8>), 10 gemm_split
+ * (k_pack_weights + k_gemm_split). */
+#define GUNET_PROF_CLASSES 11
 int gunet_profile_enable(int on);
-int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_host[GUNET_PROF_CLASSES]);
+int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_host[GUNET_PROF_CLASSES],
+                          double work_host[GUNET_PROF_CLASSES]);
 const char* gunet_profile_class_name(int cls);
 
 #ifdef __cplusplus

@@ -27,7 +27,7 @@ def main():
         n = fc[k]
         rd = 2 * ft[k] / n / 1024
         wr = wt.get(k, 0) / max(wc.get(k, 1), 1) / 1024
-        print(f'{k},{n},{rd:.3f},{wr:.3f},{rd + wr:.3f}')
+        print(f'"{k}",{n},{rd:.3f},{wr:.3f},{rd + wr:.3f}')
 
 
 if __name__ == '__main__':
