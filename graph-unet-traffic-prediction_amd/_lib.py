@@ -91,6 +91,14 @@ SIGNATURES = {
                                                 C.POINTER(GnWeightsStruct), C.c_int32, C.c_void_p,
                                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    'gunet_street_encoding_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_void_p, C.c_void_p]),
+    'gunet_edge_features_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p]),
+    'gunet_model_inputs_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    'gunet_model_inputs_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
     'gunet_profile_enable': (C.c_int, [C.c_int]),
     'gunet_profile_collect': (C.c_int, [C.POINTER(F64xP), C.POINTER(I64xP), C.POINTER(F64xP)]),
     'gunet_profile_class_name': (C.c_char_p, [C.c_int]),

@@ -3,9 +3,10 @@ import torch
 
 from .. import layers as L
 from ..layers.hybrid_gnn import Dense, GraphDownsamplingBlock, GraphUpsamplingBlock
+from .base_model import GraphBaseModel
 
 
-class GraphUNet:
+class GraphUNet(GraphBaseModel):
     """Dense in -> depth x (GN layer + 2x2 pool) -> 2 bottleneck GN layers ->
     depth x (graph upsample + skip concat + 2 GN layers) -> Dense out (no bias).
 
@@ -19,6 +20,7 @@ class GraphUNet:
 
     def __init__(self, units, out_units=8, depth=5, activation=None, layer_type=None, use_bias=False,
                  use_global=False, output_activation=None, *, min_units=128, **layer_args):
+        super().__init__()
         self.depth = depth
         self.downsampling_layers = []
         self.upsampling_layers = []
@@ -64,6 +66,8 @@ class GraphUNet:
         self.out_model.load_weights(flat, 'out_model', device)
         for prefix, layer in self._gn_layers():
             layer.load_weights(flat, prefix, device)
+        if 'cnn1/kernel' in flat and 'cnn2/kernel' in flat:
+            self.load_frontend_weights(flat, device)
         return self
 
     def named_weights(self):

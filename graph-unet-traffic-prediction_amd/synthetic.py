@@ -131,6 +131,17 @@ def graph_unet_shapes_for(units, in_features=104, out_units=96, depth=3, f_e0=16
     return shapes
 
 
+def cnn_shapes():
+    """The street-map CNN of the model's caller (models/base_model.py:263-264)."""
+    return {'cnn1/kernel': (3, 3, 1, 32), 'cnn2/kernel': (3, 3, 32, 8)}
+
+
+def street_map(mask, seed=3):
+    """uint8 street map: non-zero (1..255) on the mask, zero elsewhere."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (np.asarray(mask, dtype=bool) * rng.integers(1, 256, size=np.shape(mask))).astype(np.uint8)
+
+
 def random_weights(shapes, seed=1):
     """Glorot-uniform kernels, U(-0.1, 0.1) biases, global scales 1."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -140,6 +151,9 @@ def random_weights(shapes, seed=1):
             out[name] = np.float32(1.0)
         elif len(shp) == 1:
             out[name] = rng.uniform(-0.1, 0.1, shp).astype(np.float32)
+        elif len(shp) == 4:                                     # convolution kernel [kh, kw, in, out]
+            lim = np.sqrt(6.0 / (shp[0] * shp[1] * (shp[2] + shp[3])))
+            out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
         else:
             lim = np.sqrt(6.0 / (shp[0] + shp[1]))
             out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)

@@ -206,7 +206,38 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
                                   gunet_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * 3. Measurement -- no counterpart in the reference
+ * 3. Input assembly -- the caller of the model, models/base_model.py:274-312
+ *    (asynchronous; nothing allocated)
+ * ------------------------------------------------------------------------ */
+
+/* models/base_model.py:274-280 forward_street_encoding: street_map uint8 [height, width] / 255
+ * -> Conv2D(32, 3x3, 'SAME', relu, no bias) -> Conv2D(8, 3x3, 'SAME', relu, no bias) -> values at
+ * the node pixels node_loc int64 [N,2] (row, col).  cnn1_kernel float32 [3,3,1,32] and cnn2_kernel
+ * [3,3,32,8] in the checkpoint's layout (ky, kx, in, out).  out float32 [N,8].  Only the node
+ * pixels are evaluated (the reference computes the whole map, then gathers). */
+int gunet_street_encoding_f32(const uint8_t* street_map, int32_t height, int32_t width, const float* cnn1_kernel,
+                              const float* cnn2_kernel, const int64_t* node_loc, int64_t n_nodes, float* out,
+                              gunet_stream_t stream);
+
+/* models/base_model.py:282-285 compute_edge_features: out[e] = [encoding[sender] | encoding[receiver]],
+ * encoding float32 [N, width], edge_index int32 [E,2], out float32 [E, 2*width]. */
+int gunet_edge_features_f32(const float* encoding, int64_t n_nodes, int32_t width, const int32_t* edge_index,
+                            int64_t n_edges, float* out, gunet_stream_t stream);
+
+/* models/base_model.py:300,307-312: x[b] = [seed_nodes[b] | encoding] (float32 [B,N,seed_width+enc_width]) and
+ * global[b] = [column sums of x[b] / (300*300) | time_enc[b] | one_hot(weekday[b], 7)]
+ * (float32 [B, seed_width+enc_width+time_width+7]).  seed_nodes float32 [B,N,seed_width], encoding float32
+ * [N,enc_width] (shared by the samples of a city), time_enc float32 [B,time_width] (the last time step's
+ * encoding, x['time_enc'][:, -1]), weekday int32 [B].  The column sums are block partials added in a
+ * fixed order (float64 across blocks). */
+size_t gunet_model_inputs_workspace_bytes(int64_t n_nodes, int32_t batch, int32_t seed_width, int32_t enc_width);
+int gunet_model_inputs_f32(const float* seed_nodes, int32_t seed_width, const float* encoding, int32_t enc_width,
+                           const float* time_enc, int32_t time_width, const int32_t* weekday, int64_t n_nodes,
+                           int32_t batch, float* x, float* global_out, void* workspace, size_t workspace_bytes,
+                           gunet_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 4. Measurement -- no counterpart in the reference
  * ------------------------------------------------------------------------ */
 
 /* Per-kernel-class device timing.  While enabled, every kernel launch of the feature functions

@@ -435,6 +435,54 @@ def assemble_inputs(seed_nodes, street_encoding, edge_index, node_loc, time_enc,
     return traffic_input.astype(F32), graph
 
 
+def conv2d_same(x, kernel):
+    """tf.keras.layers.Conv2D(kernel_size=3, strides=1, padding='SAME', use_bias=False) on one image
+    x [H, W, C_in] with kernel [3, 3, C_in, C_out]: cross-correlation over a zero-padded input."""
+    h, w, _ = x.shape
+    xp = np.pad(x.astype(F32), ((1, 1), (1, 1), (0, 0)))
+    out = np.zeros((h, w, kernel.shape[3]), dtype=F32)
+    for ky in range(3):
+        for kx in range(3):
+            out += xp[ky:ky + h, kx:kx + w, :] @ kernel[ky, kx].astype(F32)
+    return out
+
+
+def forward_street_encoding(street_map, W, node_loc):
+    """models/base_model.py:274-280: uint8 street map [H, W] -> /255 -> cnn1 (3x3, 32, relu) ->
+    cnn2 (3x3, 8, relu) -> gather_nd at node_loc (row, col) -> [N, 8]."""
+    img = street_map.astype(F32)[..., None] / F32(255)                         # :276-277
+    enc = relu(conv2d_same(relu(conv2d_same(img, W['cnn1/kernel'])), W['cnn2/kernel']))   # :263-264,278
+    loc = np.asarray(node_loc, dtype=np.int64)
+    return enc[loc[:, 0], loc[:, 1]]                                           # :279
+
+
+def compute_edge_features(street_encoding, edge_index):
+    """models/base_model.py:282-285."""
+    enc = street_encoding[edge_index]
+    return np.concatenate((enc[:, 0], enc[:, 1]), axis=-1)
+
+
+def model_call(x, W, **kw):
+    """GraphBaseModel._call (models/base_model.py:287-325), inference: x is the reference's nested
+    input {'graph': {'seed_nodes', 'edge_index' (4 lists), 'node_loc'}, 'image': {'street_map'},
+    'time_enc' [1, T, 2], 'weekday' [1]} -> max(pred, 0) [N, out_units]."""
+    g = x['graph']
+    enc = forward_street_encoding(x['image']['street_map'], W, g['node_loc'])  # :293
+    x_in, graph = assemble_inputs(g['seed_nodes'], enc, g['edge_index'], g['node_loc'],
+                                  x['time_enc'], x['weekday'])                 # :294-312
+    return predict(x_in, graph, W, **kw)[0]                                    # :314,325
+
+
+def synth_street_map(mask, seed):
+    """uint8 street map: non-zero (1..255) on the mask, zero elsewhere."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (np.asarray(mask, dtype=bool) * rng.integers(1, 256, size=np.shape(mask))).astype(np.uint8)
+
+
+def cnn_shapes():
+    return {'cnn1/kernel': (3, 3, 1, 32), 'cnn2/kernel': (3, 3, 32, 8)}
+
+
 def predict(x, graph, W, **kw):
     """pred = max(GraphUNet(x, graph), 0)  (models/base_model.py:314,325)."""
     y, graph = graph_unet_forward(x, graph, W, **kw)
@@ -543,6 +591,9 @@ def make_weights(shapes, seed=1):
             W[name] = F32(1.0)
         elif len(shp) == 1:
             W[name] = rng.uniform(-0.1, 0.1, shp).astype(F32)
+        elif len(shp) == 4:                                     # convolution kernel [kh, kw, in, out]
+            lim = np.sqrt(6.0 / (shp[0] * shp[1] * (shp[2] + shp[3])))
+            W[name] = rng.uniform(-lim, lim, shp).astype(F32)
         else:
             lim = np.sqrt(6.0 / (shp[0] + shp[1]))
             W[name] = rng.uniform(-lim, lim, shp).astype(F32)

@@ -231,3 +231,35 @@ def test_synthetic_generators_match_oracle(oracle):
     x2, edges2, glob2 = synthetic.assemble_model_inputs(sn2, enc, quads, te2, wd2)
     assert np.array_equal(x, x2) and np.array_equal(graph['global'], glob2)
     assert all(np.array_equal(a, b) for a, b in zip(graph['edges'], edges2))
+
+
+def test_street_cnn_naive(oracle):
+    """conv2d_same / forward_street_encoding against element-by-element loops (tf.keras Conv2D:
+    cross-correlation, 'SAME' zero padding, kernel [kh, kw, in, out])."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    h, w = 6, 7
+    smap = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    W = oracle.make_weights(oracle.cnn_shapes(), 2)
+    k1, k2 = W['cnn1/kernel'].astype(np.float64), W['cnn2/kernel'].astype(np.float64)
+    img = smap.astype(np.float64) / 255.0
+
+    def conv(x, k):
+        out = np.zeros((h, w, k.shape[3]))
+        for y in range(h):
+            for xx in range(w):
+                for ky in range(3):
+                    for kx in range(3):
+                        yy, xc = y + ky - 1, xx + kx - 1
+                        if 0 <= yy < h and 0 <= xc < w:
+                            out[y, xx] += x[yy, xc] @ k[ky, kx]
+        return out
+
+    want = np.maximum(conv(np.maximum(conv(img[..., None], k1), 0), k2), 0)
+    loc = np.array([[0, 0], [5, 6], [2, 3], [0, 6]])
+    got = oracle.forward_street_encoding(smap, W, loc)
+    assert got.shape == (4, 8) and got.dtype == np.float32
+    assert np.abs(got - want[loc[:, 0], loc[:, 1]]).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    enc = rng.random((9, 8)).astype(np.float32)
+    e = np.array([[0, 3], [8, 8], [2, 1]], dtype=np.int32)
+    feats = oracle.compute_edge_features(enc, e)
+    assert feats.shape == (3, 16) and np.array_equal(feats[0], np.concatenate((enc[0], enc[3])))
