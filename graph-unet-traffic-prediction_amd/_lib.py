@@ -99,6 +99,14 @@ SIGNATURES = {
     'gunet_model_inputs_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_size_t, C.c_void_p]),
+    'gunet_image_to_graph': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_int64 * 2), C.c_void_p]),
+    'gunet_prediction_image_u8': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                            C.c_void_p]),
+    'gunet_error_sums_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    'gunet_error_sums_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     'gunet_profile_enable': (C.c_int, [C.c_int]),
     'gunet_profile_collect': (C.c_int, [C.POINTER(F64xP), C.POINTER(I64xP), C.POINTER(F64xP)]),
     'gunet_profile_class_name': (C.c_char_p, [C.c_int]),

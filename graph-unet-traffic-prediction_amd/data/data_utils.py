@@ -33,3 +33,29 @@ def sample_quadrant_subgraphs(edge_index, direction):
     call('gunet_quadrant_partition', ptr(e), ptr(d), n, C.byref(out), C.byref(counts),
          current_stream(e.device))
     return tuple(bufs[q][:int(counts[q])].clone() for q in range(4))
+
+
+def image_to_graph(graph_data, return_img_mask=False, add_selfloops=True):
+    """Directional maps -> graph (reference data/data_utils.py:95-150, mask_invalid_ids :84-93).
+
+    graph_data: uint8 (or bool) CUDA tensor [8, H, W], non-zero where the pixel has an edge towards
+    N, NE, E, SE, S, SW, W, NW.  Returns node_position int64 [N, 2] (row, col; raster order),
+    edge_index int32 [E, 2] ordered by (source pixel, direction), direction int64 [E] (8 = the
+    self-loop added per node), and the node mask bool [H, W] if return_img_mask."""
+    if not (isinstance(graph_data, torch.Tensor) and graph_data.is_cuda):
+        raise TypeError('graph_data must be a CUDA tensor')
+    if graph_data.dim() != 3 or graph_data.shape[0] != 8:
+        raise ValueError(f'graph_data must be [8, H, W], got {tuple(graph_data.shape)}')
+    maps = (graph_data != 0).to(torch.uint8).contiguous() if graph_data.dtype != torch.uint8 else graph_data.contiguous()
+    h, w = int(maps.shape[1]), int(maps.shape[2])
+    dev = maps.device
+    node_loc = torch.empty((h * w, 2), dtype=torch.int64, device=dev)
+    edge_index = torch.empty((9 * h * w, 2), dtype=torch.int32, device=dev)
+    direction = torch.empty((9 * h * w,), dtype=torch.int64, device=dev)
+    mask = torch.empty((h, w), dtype=torch.uint8, device=dev)
+    counts = (C.c_int64 * 2)()
+    call('gunet_image_to_graph', ptr(maps), h, w, 1 if add_selfloops else 0, ptr(node_loc), ptr(edge_index),
+         ptr(direction), ptr(mask), C.byref(counts), current_stream(dev))
+    n, e = int(counts[0]), int(counts[1])
+    out = (node_loc[:n].clone(), edge_index[:e].clone(), direction[:e].clone())
+    return out + (mask.bool(),) if return_img_mask else out

@@ -60,6 +60,23 @@ class GraphBaseModel:
     def get_seeds(self, x):
         return x['graph']['seed_nodes']
 
+    def get_targets(self, x):
+        return x['graph']['target_nodes']
+
+    def compute_metrics(self, traffic_data, pred):
+        """reference :333-351: the metric dictionary plus the leaderboard-style 'score' (the scaled MSE
+        spread over all pixels of the image) and 'rel_score' (the same for the untouched input)."""
+        from .. import evaluation
+        seed, target = self.get_seeds(traffic_data), self.get_targets(traffic_data)
+        metrics = evaluation.compute_metrics(target, pred, mask=None)
+        seed_metrics = evaluation.compute_metrics(target, seed, mask=None, score_only=True)
+        h, w = traffic_data['image']['street_map'].shape[:2]
+        n_nodes = float(pred.shape[0])
+        n_zeros = float(h * w) - n_nodes
+        metrics['score'] = metrics['mse_scaled'] * n_nodes / (n_nodes + n_zeros)
+        metrics['rel_score'] = seed_metrics['mse_scaled'] * n_nodes / (n_nodes + n_zeros) / metrics['score']
+        return metrics
+
     def _city_features(self, x, batch):
         g = x['graph']
         key = (x['image']['street_map'].data_ptr(), g['node_loc'].data_ptr(),

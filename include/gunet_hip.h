@@ -206,8 +206,8 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
                                   gunet_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * 3. Input assembly -- the caller of the model, models/base_model.py:274-312
- *    (asynchronous; nothing allocated)
+ * 3. Either side of the model -- graph construction, input assembly (models/base_model.py:274-312),
+ *    prediction image and metric sums (asynchronous and allocation-free except gunet_image_to_graph)
  * ------------------------------------------------------------------------ */
 
 /* models/base_model.py:274-280 forward_street_encoding: street_map uint8 [height, width] / 255
@@ -235,6 +235,38 @@ int gunet_model_inputs_f32(const float* seed_nodes, int32_t seed_width, const fl
                            const float* time_enc, int32_t time_width, const int32_t* weekday, int64_t n_nodes,
                            int32_t batch, float* x, float* global_out, void* workspace, size_t workspace_bytes,
                            gunet_stream_t stream);
+
+/* data/data_utils.py:84-150 image_to_graph (with mask_invalid_ids :84-93): maps uint8 [8, height, width],
+ * non-zero = the pixel has an edge in that direction (N, NE, E, SE, S, SW, W, NW; maps that would
+ * leave the image are ignored).  Nodes = pixels with at least one edge, numbered in raster order;
+ * edges ordered by (source pixel, direction), self-loops (direction 8) appended per node when
+ * add_selfloops; a target pixel that is no node maps to node 0, as in the reference.  Outputs with
+ * room for height*width nodes and 9*height*width edges: node_loc int64 [N,2] (row, col), edge_index
+ * int32 [E,2], direction int64 [E], node_mask uint8 [height, width] (may be NULL); counts_host =
+ * {N, E}.  A plan function (synchronises, allocates temporaries).  The reference divides the maps by
+ * their maximum first; for maps that are not two-valued its node set differs (pixels below the
+ * maximum are no nodes there). */
+int gunet_image_to_graph(const uint8_t* maps, int32_t height, int32_t width, int32_t add_selfloops,
+                         int64_t* node_loc, int32_t* edge_index, int64_t* direction, uint8_t* node_mask,
+                         int64_t counts_host[2], gunet_stream_t stream);
+
+/* submission.py:69-94 graph_to_image + predict_sample: pred float32 [B, N, pred_width] (pred_width =
+ * 12 time steps x channels) -> out uint8 [B, n_horizons, height, width, channels] with
+ * out[b, t, row, col, c] = clip(round_half_even(pred[b, n, channels * horizons[t] + c] * scale), 0, 255)
+ * at the node pixels node_loc int64 [N,2] and 0 elsewhere.  horizons int32 [n_horizons] on the
+ * device (the reference takes [0, 1, 2, 5, 8, 11]). */
+int gunet_prediction_image_u8(const float* pred, int64_t n_nodes, int32_t pred_width, int32_t batch,
+                              const int64_t* node_loc, int32_t height, int32_t width, const int32_t* horizons,
+                              int32_t n_horizons, int32_t channels, float scale, uint8_t* out,
+                              gunet_stream_t stream);
+
+/* evaluation.py:173-244 compute_metrics, graph format: the sums every metric there is a ratio of.
+ * y_true, y_pred float32 [B, N, width]; sums float64 [B, 2, width]: sums[b, 0, c] = sum_n (t - p)^2,
+ * sums[b, 1, c] = sum_n |t - p|, added in a fixed order (float32 inside a block of rows, float64
+ * across blocks).  These are also the metric numerators a multi-GPU run all-reduces. */
+size_t gunet_error_sums_workspace_bytes(int64_t n_rows, int32_t batch, int32_t width);
+int gunet_error_sums_f32(const float* y_true, const float* y_pred, int64_t n_rows, int32_t width, int32_t batch,
+                         double* sums, void* workspace, size_t workspace_bytes, gunet_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Measurement -- no counterpart in the reference

@@ -483,6 +483,54 @@ def cnn_shapes():
     return {'cnn1/kernel': (3, 3, 1, 32), 'cnn2/kernel': (3, 3, 32, 8)}
 
 
+def predict_sample_image(pred, img_mask, data_scale=255):
+    """submission.py:69-94: scatter the node predictions [N, 96] to the image, split into 12 time
+    steps, keep steps [0, 1, 2, 5, 8, 11], round(x * scale) -> uint8 [6, H, W, 8].  (tf.round is
+    round-half-even; out-of-range values, which tf.cast leaves undefined, are clipped here.)"""
+    h, w = img_mask.shape
+    img = np.zeros((h, w, pred.shape[1]), dtype=F32)
+    img[img_mask] = pred                                                       # :75-76 (raster order)
+    steps = np.stack(np.split(img, 12, axis=-1))                               # :87
+    steps = steps[[0, 1, 2, 5, 8, 11]]                                         # :91
+    return np.clip(np.rint(steps * F32(data_scale)), 0, 255).astype(np.uint8)  # :92-93
+
+
+def compute_metrics(y_true, y_pred, data_scale=255, score_only=False):
+    """evaluation.py:173-244 for graph-format tensors [N, features * time] (mask=None):
+    tf.keras.losses.MSE / MAE = mean over the last axis, then reduce_mean over the nodes."""
+    t, p = y_true.astype(np.float64), y_pred.astype(np.float64)
+    ts, ps = t * data_scale, p * data_scale                                    # :193-194
+    mse = np.mean(np.mean((t - p) ** 2, axis=-1))                              # :203
+    mse_scaled = np.mean(np.mean((ts - ps) ** 2, axis=-1))                     # :204
+    if score_only:
+        return {'mse_scaled': mse_scaled}                                      # :206-207
+    speed, vol = slice(1, 8, 2), slice(0, 8, 2)                                # data/__init__.py:6-7
+    out = {
+        'mse': mse,
+        'mae': np.mean(np.mean(np.abs(t - p), axis=-1)),                       # :209
+        'mse_scaled': mse_scaled,
+        'mae_scaled': np.mean(np.mean(np.abs(ts - ps), axis=-1)),              # :210-211
+        'mae_scaled_speed': np.mean(np.mean(np.abs(ts[..., speed] - ps[..., speed]), axis=-1)),   # :212-215
+        'mae_scaled_volume': np.mean(np.mean(np.abs(ts[..., vol] - ps[..., vol]), axis=-1)),      # :216-219
+        'rmse_scaled': np.sqrt(mse_scaled),                                    # :220
+    }
+    ts12, ps12 = np.split(ts, 12, axis=-1), np.split(ps, 12, axis=-1)          # :232-233
+    for i in (0, 1, 2, 5, 8, 11):                                              # :235-242
+        out[f'mse_scaled_{(i + 1) * 5}_min'] = np.mean(np.mean((ts12[i] - ps12[i]) ** 2, axis=-1))
+    return {k: float(v) for k, v in out.items()}
+
+
+def model_compute_metrics(seed, target, pred, height, width):
+    """GraphBaseModel.compute_metrics (models/base_model.py:333-351)."""
+    metrics = compute_metrics(target, pred)
+    seed_metrics = compute_metrics(target, seed, score_only=True)
+    n_nodes = float(pred.shape[0])
+    n_zeros = float(height * width) - n_nodes
+    metrics['score'] = metrics['mse_scaled'] * n_nodes / (n_nodes + n_zeros)
+    metrics['rel_score'] = float(seed_metrics['mse_scaled']) * n_nodes / (n_nodes + n_zeros) / metrics['score']
+    return metrics
+
+
 def predict(x, graph, W, **kw):
     """pred = max(GraphUNet(x, graph), 0)  (models/base_model.py:314,325)."""
     y, graph = graph_unet_forward(x, graph, W, **kw)

@@ -114,3 +114,67 @@ def test_model_inputs(amd, oracle):
     with pytest.raises(amd.GunetError):
         lib.call('gunet_model_inputs_f32', lib.ptr(to_dev(seed)), 96, lib.ptr(to_dev(enc)), 8, lib.ptr(t_last), 2,
                  lib.ptr(to_dev(wd, torch.int32)), n, batch, lib.ptr(xin), lib.ptr(glob), lib.ptr(ws), 16, None)
+
+
+def test_image_to_graph(amd, oracle):
+    """Graph construction from the 8 directional maps: bit-exact with the oracle, incl. maps that
+    point out of the image (masked) and the self-loop option."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    for (h, w, dens) in [(9, 14, 0.6), (33, 27, 0.4), (495, 436, 0.45)]:
+        mask = rng.random((h, w)) < dens
+        maps = oracle.directional_maps_from_mask(mask).astype(np.uint8)
+        if h < 100:
+            maps[:, 0, :] |= 1          # edges leaving the image through every border
+            maps[:, -1, :] |= 1
+            maps[:, :, 0] |= 1
+            maps[:, :, -1] |= 1
+            maps = maps * np.uint8(255)   # 0 / 255 valued
+        for selfloops in (True, False):
+            want_loc, want_ei, want_dir, want_mask = oracle.image_to_graph(maps.copy(), add_selfloops=selfloops)
+            loc, ei, direction, m = amd.data_utils.image_to_graph(to_dev(maps), return_img_mask=True,
+                                                                  add_selfloops=selfloops)
+            assert np.array_equal(loc.cpu().numpy(), want_loc)
+            assert np.array_equal(ei.cpu().numpy(), want_ei)
+            assert np.array_equal(direction.cpu().numpy(), want_dir)
+            assert np.array_equal(m.cpu().numpy(), want_mask)
+    empty = amd.data_utils.image_to_graph(torch.zeros((8, 5, 6), dtype=torch.uint8, device='cuda'))
+    assert empty[0].shape == (0, 2) and empty[1].shape == (0, 2) and empty[2].shape == (0,)
+
+
+def test_prediction_image_and_metrics(amd, oracle):
+    rng = np.random.Generator(np.random.PCG64(12))
+    h, w = 21, 17
+    mask = rng.random((h, w)) < 0.5
+    node_loc = np.stack(np.nonzero(mask), axis=-1).astype(np.int64)
+    n = node_loc.shape[0]
+    pred = (rng.random((2, n, 96), dtype=np.float32) * np.float32(1.2)).astype(np.float32)    # some above 1 -> clip
+    pred[0, :5, :8] = np.array([0.5, 1.5, 2.5, 3.5, 254.5], dtype=np.float32)[:, None] / np.float32(255)   # ties
+    got = amd.submission.graph_to_image(to_dev(pred), to_dev(node_loc, torch.int64), h, w)
+    assert tuple(got.shape) == (2, 6, h, w, 8) and got.dtype == torch.uint8
+    for b in range(2):
+        assert np.array_equal(got[b].cpu().numpy(), oracle.predict_sample_image(pred[b], mask))
+    one = amd.submission.graph_to_image(to_dev(pred[1]), to_dev(node_loc, torch.int64), h, w)
+    assert torch.equal(one, got[1])
+
+    target = rng.random((n, 96), dtype=np.float32)
+    seed = rng.random((n, 96), dtype=np.float32)
+    want = oracle.compute_metrics(target, pred[0])
+    have = amd.evaluation.compute_metrics(to_dev(target), to_dev(pred[0]))
+    assert set(have) == set(want) and len(want) == 13
+    for k in want:
+        assert abs(have[k] - want[k]) <= 1e-5 * abs(want[k]), k
+    so = amd.evaluation.compute_metrics(to_dev(target), to_dev(seed), score_only=True)
+    assert list(so) == ['mse_scaled']
+    model = amd.GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                          use_bias=True, use_global=True)
+    data = {'graph': {'seed_nodes': to_dev(seed), 'target_nodes': to_dev(target)},
+            'image': {'street_map': torch.zeros((h, w), dtype=torch.uint8, device='cuda')}}
+    full = model.compute_metrics(data, to_dev(pred[0]))
+    want_full = oracle.model_compute_metrics(seed, target, pred[0], h, w)
+    for k in ('score', 'rel_score', 'mse', 'mae_scaled_speed', 'mse_scaled_60_min'):
+        assert abs(full[k] - want_full[k]) <= 1e-5 * abs(want_full[k]), k
+    # batched sums = per-sample sums
+    sums = amd.evaluation.error_sums(to_dev(np.stack((target, seed))), to_dev(pred))
+    assert torch.equal(sums[0], amd.evaluation.error_sums(to_dev(target), to_dev(pred[0])))
+    with pytest.raises(NotImplementedError):
+        amd.evaluation.compute_metrics(to_dev(target), to_dev(seed), mask=torch.ones(1))

@@ -263,3 +263,34 @@ def test_street_cnn_naive(oracle):
     e = np.array([[0, 3], [8, 8], [2, 1]], dtype=np.int32)
     feats = oracle.compute_edge_features(enc, e)
     assert feats.shape == (3, 16) and np.array_equal(feats[0], np.concatenate((enc[0], enc[3])))
+
+
+def test_prediction_image_and_metrics_known_answers(oracle):
+    """Hand-derived values for the post-processing restatements (submission.py:69-94,
+    evaluation.py:173-244)."""
+    mask = np.array([[True, False], [False, True]])
+    pred = np.zeros((2, 96), dtype=np.float32)
+    pred[0, 0] = 0.5 / 255      # tie -> even -> 0
+    pred[0, 1] = 1.5 / 255      # tie -> even -> 2
+    pred[0, 8 * 5 + 3] = 0.4    # step 5 is kept as index 3 -> 102
+    pred[1, 8 * 3] = 1.0        # step 3 is dropped
+    pred[1, 8 * 11 + 7] = 2.0   # clipped to 255
+    img = oracle.predict_sample_image(pred, mask)
+    assert img.shape == (6, 2, 2, 8) and img.dtype == np.uint8
+    assert img[0, 0, 0, 0] == 0 and img[0, 0, 0, 1] == 2 and img[3, 0, 0, 3] == 102
+    assert img[5, 1, 1, 7] == 255 and img[:, 0, 1].max() == 0 and img[:, 1, 0].max() == 0
+    assert int(img.astype(np.int64).sum()) == 2 + 102 + 255
+    t = np.zeros((2, 96), dtype=np.float32)
+    p = np.zeros((2, 96), dtype=np.float32)
+    p[0, 1] = 1.0               # speed column of the first step
+    p[1, 8 * 11] = 2.0          # volume column of the last step
+    m = oracle.compute_metrics(t, p)
+    assert abs(m['mse'] - 5.0 / 192) < 1e-12 and abs(m['mae'] - 3.0 / 192) < 1e-12
+    assert abs(m['mse_scaled'] - 255.0 ** 2 * 5.0 / 192) < 1e-6
+    assert abs(m['mae_scaled_speed'] - 255.0 / 8) < 1e-9        # columns 1,3,5,7 of 2 rows
+    assert m['mae_scaled_volume'] == 0.0                         # columns 0,2,4,6: the last step is not in them
+    assert abs(m['mse_scaled_5_min'] - 255.0 ** 2 / 16) < 1e-6 and abs(m['mse_scaled_60_min'] - 255.0 ** 2 * 4 / 16) < 1e-6
+    assert m['mse_scaled_30_min'] == 0.0 and abs(m['rmse_scaled'] - np.sqrt(m['mse_scaled'])) < 1e-12
+    full = oracle.model_compute_metrics(np.ones_like(t), t, p, 10, 10)
+    assert abs(full['score'] - m['mse_scaled'] * 2 / 100) < 1e-9
+    assert abs(full['rel_score'] - (255.0 ** 2) / m['mse_scaled']) < 1e-9
