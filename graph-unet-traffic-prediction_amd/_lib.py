@@ -33,7 +33,8 @@ class QuadGraphStruct(C.Structure):
                 ('n_edges', C.c_int32 * 4),
                 ('edge_index', C.c_void_p * 4),
                 ('rowptr', C.c_void_p * 4),
-                ('perm', C.c_void_p * 4)]
+                ('perm', C.c_void_p * 4),
+                ('in_table', C.c_void_p)]
 
 
 class GnWeightsStruct(C.Structure):
@@ -62,6 +63,7 @@ SIGNATURES = {
                                   C.c_void_p]),
     'gunet_csr_from_keys': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    'gunet_in_edge_table': (C.c_int, [C.POINTER(QuadGraphStruct), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     'gunet_cluster_ids': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_int64), C.c_void_p]),
     'gunet_pool_edges': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

@@ -144,6 +144,14 @@ struct GemmArgs {
   int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + ceil(n_rows / 32) - 1
   int colsum_ld;              //   floats (0 = 32*NT), this launch's columns start at out_col0
   int relu;
+  // Gathered last segment (weights-resident kernel only): when gather_table is set, the last
+  // segment (k = 128) is not read from seg[].a; row v's column block q is formed while loading as
+  // gather_scale * (sum over j of row gather_table[(v * 4 + q) * 3 + j] (>= 0, in that order) of
+  // gather_src[q], a [B][gather_rows[q]][32] tensor).
+  const int32_t* gather_table;
+  const float* gather_src[4];
+  int gather_rows[4];
+  float gather_scale;
 };
 
 constexpr int kBM = 128;
@@ -327,11 +335,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
 // loads and masked in the epilogue.  Column sums: one partial row per wave (its whole run).
 constexpr int kResWaves = 12;
 constexpr int kResThreads = 64 * kResWaves;
+constexpr int kResGatherWaves = 8;   // the gathering variant needs more registers per wave
+constexpr int kResGatherThreads = 64 * kResGatherWaves;
 constexpr size_t kResMaxLds = 160 * 1024;
 
-template <int NT, int NKT>
-__global__ __launch_bounds__(kResThreads) void k_gemm_resident(GemmArgs g, int groups_per_sample, int wps, int gpw,
+template <int NT, int NKT, bool GATHER>
+__global__ __launch_bounds__(GATHER ? kResGatherThreads : kResThreads) void k_gemm_resident(GemmArgs g, int groups_per_sample, int wps, int gpw,
                                                                int batch) {
+  static_assert(!GATHER || (NT == 4 && NKT == 8), "the gathered segment is K tiles 4..7 of a 128-column launch");
+  constexpr int kWaves = GATHER ? kResGatherWaves : kResWaves;
   constexpr int BN = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) float res_smem[];
   // Weight image: for K tile kt, 8-row chunk c and column tile n, one 1 KiB piece in lane order:
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(kResThreads) void k_gemm_resident(GemmArgs g, int g
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float* w = sg.w[t];
-        for (int i = tid; i < sg.k * 8; i += kResThreads) {
+        for (int i = tid; i < sg.k * 8; i += kWaves * 64) {
           const int row = kbase + (i >> 3), c4 = i & 7;
           const float4 v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
           // row = 8 * chunk + 4 * half + j
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(kResThreads) void k_gemm_resident(GemmArgs g, int g
   }
   __syncthreads();
 
-  const int wid = blockIdx.x * kResWaves + wave;
+  const int wid = blockIdx.x * kWaves + wave;
   const int b = wid / wps;
   if (b >= batch) return;
   const int slot = wid - b * wps;
@@ -455,6 +467,52 @@ __global__ __launch_bounds__(kResThreads) void k_gemm_resident(GemmArgs g, int g
     }
   };
 
+  // Gathered tiles: the node's table row (12 edge positions) is fetched at the top of its group; the
+  // (up to) three source rows of quadrant q are requested one K tile ahead -- the first two into
+  // `gbuf`, the third into the operand buffer a0, which is idle during these tiles -- and summed
+  // into a1 right before the MFMAs of that tile.
+  int4 tab[3];
+  float4 gbuf[2][4];
+  auto load_table = [&](int grp_) {
+    int row = grp_ * kRowGroup + li;
+    row = row < g.n_rows ? row : g.n_rows - 1;
+    const int4* tp = reinterpret_cast<const int4*>(g.gather_table) + static_cast<int64_t>(row) * 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tab[i] = tp[i];
+  };
+  auto tab_at = [&](int i) {   // i = 3 * q + j, compile-time after unrolling
+    const int4 t = tab[i >> 2];
+    return (i & 3) == 0 ? t.x : ((i & 3) == 1 ? t.y : ((i & 3) == 2 ? t.z : t.w));
+  };
+  auto gather_issue = [&](int q, float4 (&third)[4]) {
+    const char* sb = reinterpret_cast<const char*>(g.gather_src[q]);
+    const uint32_t base = static_cast<uint32_t>(b) * static_cast<uint32_t>(g.gather_rows[q]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int id = tab_at(3 * q + j);
+      const uint32_t voff = ((base + static_cast<uint32_t>(id > 0 ? id : 0)) * 32u + 4u * static_cast<uint32_t>(lh)) * 4u;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(sb + voff + 32u * c);
+        if (j < 2)
+          gbuf[j][c] = v;
+        else
+          third[c] = v;
+      }
+    }
+  };
+  auto gather_reduce = [&](int q, const float4 (&third)[4], float4 (&a)[4]) {
+    const bool ok0 = tab_at(3 * q) >= 0, ok1 = tab_at(3 * q + 1) >= 0, ok2 = tab_at(3 * q + 2) >= 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok0) s = gbuf[0][c];
+      if (ok1) { s.x += gbuf[1][c].x; s.y += gbuf[1][c].y; s.z += gbuf[1][c].z; s.w += gbuf[1][c].w; }
+      if (ok2) { s.x += third[c].x; s.y += third[c].y; s.z += third[c].z; s.w += third[c].w; }
+      a[c] = make_float4(s.x * g.gather_scale, s.y * g.gather_scale, s.z * g.gather_scale, s.w * g.gather_scale);
+    }
+  };
+
   uint32_t cur = lane_row(grp);
   float4 a0[4], a1[4];
   load_tile(cur, 0, a0);
@@ -465,19 +523,51 @@ __global__ __launch_bounds__(kResThreads) void k_gemm_resident(GemmArgs g, int g
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    if constexpr (GATHER) {
+      load_table(grp);
+      load_tile(cur, 1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(cur, 2, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(cur, 3, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(2, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      gather_issue(0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(3, a1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kt = 0; kt < NKT; kt += 2) {
-      load_tile(cur, kt + 1, a1);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(kt, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < NKT)
-        load_tile(cur, kt + 2, a0);
-      else
-        load_tile(nxt, 0, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(kt + 1, a1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < 4; ++q) {
+        gather_reduce(q, a0, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < 3)
+          gather_issue(q + 1, a0);
+        else
+          load_tile(nxt, 0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(4 + q, a1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; kt += 2) {
+        load_tile(cur, kt + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(kt, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < NKT)
+          load_tile(cur, kt + 2, a0);
+        else
+          load_tile(nxt, 0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(kt + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // Take delivery of the next group's first tile now, while only loads are outstanding: a wait
     // placed after the stores below would have to cover them as well (loads and stores share one
@@ -785,6 +875,11 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   for (int s = 0; s < g.n_seg; ++s)   // 32-bit byte offsets into every operand segment and the output
     if (batch * g.n_rows * g.seg[s].lda * 4 >= (int64_t{1} << 32)) return false;
   if (batch * (g.out_rows ? g.out_rows : g.n_rows) * g.ldo * 4 >= (int64_t{1} << 32)) return false;
+  if (g.gather_table != nullptr) {   // K tiles 4..7 of a 128-column launch, 32-bit offsets into the sources
+    if (nt != 4 || kt != 8 || g.n_seg < 2 || g.seg[g.n_seg - 1].k != 128) return false;
+    for (int q = 0; q < 4; ++q)
+      if (batch * g.gather_rows[q] * 128 >= (int64_t{1} << 32)) return false;
+  }
   return batch * ceil_div(g.n_rows, kRowGroup) < (1 << 30);
 }
 
@@ -805,10 +900,10 @@ struct ResidentSplit {
   int groups, wps, gpw;
 };
 
-inline ResidentSplit resident_split(int n_rows, int64_t batch) {
+inline ResidentSplit resident_split(int n_rows, int64_t batch, bool gather) {
   ResidentSplit r;
   r.groups = static_cast<int>(ceil_div(n_rows, kRowGroup));
-  const int64_t waves = static_cast<int64_t>(device_cu_count()) * kResWaves;
+  const int64_t waves = static_cast<int64_t>(device_cu_count()) * (gather ? kResGatherWaves : kResWaves);
   const int per_sample = static_cast<int>(std::max<int64_t>(1, waves / batch));
   r.gpw = static_cast<int>(ceil_div(r.groups, std::min(per_sample, r.groups)));
   r.wps = static_cast<int>(ceil_div(r.groups, r.gpw));
@@ -825,11 +920,11 @@ inline bool takes_resident(const GemmArgs& g, int nt, int64_t batch, const void*
 // Rows of column-sum partials per sample that a launch writes (from colsum_tile0 on).
 inline int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
   if (g.n_rows == 0) return 0;
-  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch).wps;
+  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, g.gather_table != nullptr).wps;
   return static_cast<int>(ceil_div(g.n_rows, kRowGroup));
 }
 
-template <int NT, int NKT>
+template <int NT, int NKT, bool GATHER = false>
 int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   static bool raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
   const size_t lds = resident_lds_bytes(NT, NKT);
@@ -837,19 +932,21 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   GUNET_HIP_TRY(hipGetDevice(&dev));
   GUNET_REQUIRE(dev >= 0 && dev < 64, "launch_gemm: device index %d", dev);
   if (!raised[dev]) {
-    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT>),
+    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResMaxLds)));
     raised[dev] = true;
   }
-  const ResidentSplit sp = resident_split(g.n_rows, batch);
-  const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kResWaves));
-  k_gemm_resident<NT, NKT><<<blocks, kResThreads, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw, static_cast<int>(batch));
+  constexpr int kWaves = GATHER ? kResGatherWaves : kResWaves;
+  const ResidentSplit sp = resident_split(g.n_rows, batch, GATHER);
+  const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kWaves));
+  k_gemm_resident<NT, NKT, GATHER><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw, static_cast<int>(batch));
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
 int launch_gemm_resident(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
   const int kt = gemm_ktiles(g);
+  if (g.gather_table != nullptr) return launch_resident_inst<4, 8, true>(g, batch, stream);
   if (nt == 4) return kt == 4 ? launch_resident_inst<4, 4>(g, batch, stream) : launch_resident_inst<4, 8>(g, batch, stream);
   return kt == 4 ? launch_resident_inst<3, 4>(g, batch, stream) : launch_resident_inst<3, 8>(g, batch, stream);
 }
@@ -1779,7 +1876,51 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_TRY(launch_edge_mlp(a, ut, graph, edges, ws.n_eblk, batch, stream));
   }
 
-  if (n > 0) {  // neighbour aggregation (hybrid_gnn.py:110-113)
+  // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
+  GemmArgs g = {};
+  int64_t row_of[3];
+  {
+    int s = 0;
+    g.seg[s].a = x;
+    g.seg[s].lda = c_a;
+    g.seg[s].k = c_a;
+    row_of[s++] = 0;
+    if (c_skip) {
+      g.seg[s].a = x_skip;
+      g.seg[s].lda = c_skip;
+      g.seg[s].k = c_skip;
+      row_of[s++] = c_a;
+    }
+    g.seg[s].a = ws.agg;
+    g.seg[s].lda = U;
+    g.seg[s].k = U;
+    row_of[s++] = w->c_in;
+    g.n_seg = s;
+    for (int i = 0; i < s; ++i) g.seg[i].ldw = U;
+    g.n_rows = n;
+    g.relu = relu;
+  }
+  // With a per-node table of incoming edges the GEMM sums the messages while it loads them
+  // (same order and scale as k_aggregate), and the aggregated tensor never exists.
+  bool fused = false;
+  if (graph->in_table != nullptr && U == 128 && n > 0) {
+    GemmArgs gg = g;
+    gg.seg[g.n_seg - 1].a = nullptr;
+    gg.seg[g.n_seg - 1].lda = 0;
+    gg.gather_table = graph->in_table;
+    for (int q = 0; q < 4; ++q) {
+      gg.gather_src[q] = edges_out[q];
+      gg.gather_rows[q] = graph->n_edges[q];
+    }
+    gg.gather_scale = 1.0f / (3 + 1);
+    gg.ldo = U;
+    if (takes_resident(gg, 4, batch, ws.wpack)) {
+      g = gg;
+      fused = true;
+    }
+  }
+
+  if (n > 0 && !fused) {  // neighbour aggregation (hybrid_gnn.py:110-113)
     AggArgs a;
     for (int q = 0; q < 4; ++q) {
       a.rowptr[q] = graph->rowptr[q];
@@ -1801,34 +1942,10 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     GUNET_LAUNCH_CHECK();
   }
 
-  int n_partials = 0;   // column-sum partial rows per sample
-  {  // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
-    GemmArgs g = {};
-    int s = 0;
-    int64_t row_of[3];
-    g.seg[s].a = x;
-    g.seg[s].lda = c_a;
-    g.seg[s].k = c_a;
-    row_of[s++] = 0;
-    if (c_skip) {
-      g.seg[s].a = x_skip;
-      g.seg[s].lda = c_skip;
-      g.seg[s].k = c_skip;
-      row_of[s++] = c_a;
-    }
-    g.seg[s].a = ws.agg;
-    g.seg[s].lda = U;
-    g.seg[s].k = U;
-    row_of[s++] = w->c_in;
-    g.n_seg = s;
-    for (int i = 0; i < s; ++i) g.seg[i].ldw = U;
-    g.n_rows = n;
-    g.relu = relu;
-    auto w_of = [&](int seg, int col) { return w->node_w + row_of[seg] * U + col; };
-    n_partials = columns_colsum_rows(g, U, batch, ws.wpack);
-    g.colsum_tiles = n_partials;
-    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
-  }
+  auto w_of = [&](int seg, int col) { return w->node_w + row_of[seg] * U + col; };
+  const int n_partials = columns_colsum_rows(g, U, batch, ws.wpack);
+  g.colsum_tiles = n_partials;
+  GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
 
   return launch_global_update(p, ut, global_in, n_partials, relu, batch, ws, global_out, stream);
 }

@@ -565,6 +565,26 @@ int check_err_flag(const DevBuf& err, hipStream_t stream, const char* what) {
   return GUNET_OK;
 }
 
+// ---------------------------------------------------------------- in-edge table
+
+struct CsrPtrs {
+  const int32_t* rowptr[4];
+  const int32_t* perm[4];
+};
+
+// table[v][q][j] = position (in quadrant q's edge list) of the j-th incoming edge of node v, or -1
+__global__ void k_in_table(CsrPtrs p, int n_nodes, int32_t* __restrict__ table, int32_t* __restrict__ max_deg) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<int64_t>(n_nodes) * 4) return;
+  const int v = static_cast<int>(idx >> 2), q = static_cast<int>(idx & 3);
+  const int32_t* rowptr = q == 0 ? p.rowptr[0] : q == 1 ? p.rowptr[1] : q == 2 ? p.rowptr[2] : p.rowptr[3];
+  const int32_t* perm = q == 0 ? p.perm[0] : q == 1 ? p.perm[1] : q == 2 ? p.perm[2] : p.perm[3];
+  const int beg = rowptr[v], deg = rowptr[v + 1] - beg;
+  if (deg > 0) atomicMax(max_deg, deg);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) table[idx * 3 + j] = j < deg ? perm[beg + j] : -1;
+}
+
 }  // namespace
 }  // namespace gunet
 
@@ -698,6 +718,31 @@ int gunet_upsample_edges(const int64_t* coarse_loc, int64_t n_coarse, const int6
   GUNET_TRY(check_err_flag(err, stream, "upsample_edges: parent id outside the coarse graph"));
   return partition4(mask.as<uint8_t>(), n_fine, nullptr, parent, static_cast<int32_t>(n_coarse),
                     out_edges, counts_host, stream);
+}
+
+int gunet_in_edge_table(const gunet_quadgraph* graph, int32_t* table, int32_t* max_in_degree_host,
+                        gunet_stream_t stream_) {
+  hipStream_t stream = as_stream(stream_);
+  GUNET_REQUIRE(graph && max_in_degree_host, "in_edge_table: null argument");
+  *max_in_degree_host = 0;
+  GUNET_REQUIRE(graph->n_nodes >= 0, "in_edge_table: negative node count");
+  if (graph->n_nodes == 0) return GUNET_OK;
+  GUNET_REQUIRE(table, "in_edge_table: null table");
+  CsrPtrs p;
+  for (int q = 0; q < 4; ++q) {
+    GUNET_REQUIRE(graph->rowptr[q] && (graph->n_edges[q] == 0 || graph->perm[q]), "in_edge_table: null CSR %d", q);
+    p.rowptr[q] = graph->rowptr[q];
+    p.perm[q] = graph->perm[q];
+  }
+  DevBuf md;
+  GUNET_HIP_TRY(md.alloc(sizeof(int32_t)));
+  GUNET_HIP_TRY(hipMemsetAsync(md.as<int32_t>(), 0, sizeof(int32_t), stream));
+  const int64_t work = static_cast<int64_t>(graph->n_nodes) * 4;
+  k_in_table<<<grid_for(work), kThreads, 0, stream>>>(p, graph->n_nodes, table, md.as<int32_t>());
+  GUNET_LAUNCH_CHECK();
+  GUNET_HIP_TRY(hipMemcpyAsync(max_in_degree_host, md.as<int32_t>(), sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GUNET_HIP_TRY(hipStreamSynchronize(stream));
+  return GUNET_OK;
 }
 
 }  // extern "C"

@@ -90,6 +90,16 @@ class QuadGraph:
             s.edge_index[q] = self.edge_index[q].data_ptr()
             s.rowptr[q] = self.rowptr[q].data_ptr()
             s.perm[q] = self.perm[q].data_ptr()
+        # per-node table of the (at most 3) incoming edges per quadrant, when the graph allows it
+        self.in_table = None
+        if self.n_nodes > 0:
+            table = torch.empty((self.n_nodes, 4, 3), dtype=torch.int32, device=self.device)
+            max_deg = C.c_int32(0)
+            call('gunet_in_edge_table', C.byref(s), ptr(table), C.byref(max_deg), stream)
+            self.max_in_degree = int(max_deg.value)
+            if self.max_in_degree <= 3:
+                self.in_table = table
+                s.in_table = table.data_ptr()
         self.struct = s
         self._ws_bytes = {}
 

@@ -143,14 +143,28 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
                             const float* bias, int32_t n_out, int32_t activation, float* out,
                             void* workspace, size_t workspace_bytes, gunet_stream_t stream);
 
-/* One quadrant graph: 4 reference-ordered edge lists and their receiver CSRs. */
+/* One quadrant graph: 4 reference-ordered edge lists and their receiver CSRs.
+ * in_table (optional, NULL = absent): for graphs whose nodes have at most 3 incoming edges per
+ * quadrant (every pixel-grid quadrant graph and its 2x2 poolings), the incoming edge positions of
+ * node v in quadrant q at in_table[(v * 4 + q) * 3 + 0..2], ascending, -1 padded
+ * (gunet_in_edge_table).  With it the node MLP sums the messages while it loads them and the
+ * separate aggregation pass is skipped. */
 typedef struct gunet_quadgraph {
   int32_t n_nodes;
   int32_t n_edges[4];
   const int32_t* edge_index[4]; /* [E_q, 2] sender, receiver */
   const int32_t* rowptr[4];     /* [n_nodes + 1] */
   const int32_t* perm[4];       /* [E_q] */
+  const int32_t* in_table;      /* [n_nodes, 4, 3] or NULL */
 } gunet_quadgraph;
+
+/* Per-node table of incoming edges of a quadrant graph (see gunet_quadgraph.in_table): fills
+ * table int32 [n_nodes, 4, 3] from graph->rowptr / perm and returns the largest in-degree found in
+ * *max_in_degree_host; the table is only valid when that is <= 3.  graph->in_table is not read.
+ * A plan function (synchronises).  No counterpart in the reference (index side of
+ * tf.math.unsorted_segment_sum, layers/hybrid_gnn.py:110). */
+int gunet_in_edge_table(const gunet_quadgraph* graph, int32_t* table, int32_t* max_in_degree_host,
+                        gunet_stream_t stream);
 
 /* Parameters of one GeoQuadrantGCN (layers/hybrid_gnn.py:20-70), in the layout
  * of the reference's checkpoint: Dense kernels [in, out] row-major, one set per

@@ -306,3 +306,39 @@ def test_matmul_modes(amd, oracle, mode, tol):
         assert rel_err(got_y, want_y) > 1e-5           # the mode really is on
     with pytest.raises(amd.GunetError):
         amd._lib.call('gunet_set_matmul_mode', 17)
+
+
+def test_gn_layer_arbitrary_graph(amd, oracle):
+    """Edge lists that are no pixel grid (random senders and receivers, in-degree far above 3, some
+    nodes without incoming edges, one empty quadrant): the layer must not rely on grid structure."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 300
+    quads = [rng.integers(0, n - 40, (m, 2)).astype(np.int32) for m in (1500, 37, 0, 2600)]
+    x = (rng.random((n, 128)) - 0.4).astype(np.float32)
+    graph = {'edge_index': quads, 'node_loc': np.zeros((n, 2), np.int64),
+             'edges': [rng.random((q.shape[0], 32)).astype(np.float32) for q in quads],
+             'global': rng.random((1, 128)).astype(np.float32)}
+    W = _layer_weights(oracle, 'L', 128, 32, 128)
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
+    got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L')
+    qg = amd.plan.get_quadgraph(graph_to_dev(graph)['edge_index'], n)
+    assert qg.max_in_degree > 3 and qg.in_table is None
+    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    for q in range(4):
+        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+
+
+def test_in_edge_table(amd, oracle):
+    """The per-node table of incoming edges lists, per quadrant, the edge positions whose receiver is
+    the node, ascending, -1 padded; road graphs and their poolings never exceed 3."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(30, 26, 0.7, 5)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    qg = amd.plan.QuadGraph([to_dev(q, torch.int32) for q in quads], node_loc.shape[0])
+    assert 1 <= qg.max_in_degree <= 3
+    table = qg.in_table.cpu().numpy()
+    for q in range(4):
+        recv = quads[q][:, 1]
+        for v in range(node_loc.shape[0]):
+            want = np.flatnonzero(recv == v)
+            assert list(table[v, q, :want.size]) == list(want) and (table[v, q, want.size:] == -1).all()
