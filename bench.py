@@ -44,10 +44,11 @@ def parse_args():
     return ap.parse_args()
 
 
-GEMM_CLASSES = ('gemm_tiled', 'gemm_resident_k128', 'gemm_resident_k256', 'gemm_split')
+GEMM_CLASSES = ('gemm_tiled', 'gemm_resident_k128', 'gemm_resident_k256', 'gemm_resident_k384', 'gemm_split')
 MFMA_CLASSES = GEMM_CLASSES + ('edge_mlp',)
 KERNEL_OF_CLASS = {'gemm_tiled': 'k_gemm_f32', 'gemm_resident_k128': 'k_gemm_resident<*, 4>',
-                   'gemm_resident_k256': 'k_gemm_resident<*, 8>', 'gemm_split': 'k_gemm_split', 'edge_mlp': 'k_edge_mlp',
+                   'gemm_resident_k256': 'k_gemm_resident<*, 8>', 'gemm_resident_k384': 'k_gemm_resident<*, 12>',
+                   'gemm_split': 'k_gemm_split', 'edge_mlp': 'k_edge_mlp',
                    'aggregate': 'k_aggregate', 'segment_reduce': 'k_segment_reduce', 'layer_prologue': 'k_layer_prologue',
                    'global_update': 'k_global_update', 'gather_rows': 'k_gather_rows', 'dense_naive': 'k_dense_naive'}
 

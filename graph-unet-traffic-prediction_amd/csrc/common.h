@@ -80,6 +80,7 @@ enum ProfClass {
   kProfGemmRes128,
   kProfGemmRes256,
   kProfGemmSplit,
+  kProfGemmRes384,
   kProfCount
 };
 static_assert(kProfCount == GUNET_PROF_CLASSES, "profiler class table out of step with the header");

@@ -335,15 +335,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
 // loads and masked in the epilogue.  Column sums: one partial row per wave (its whole run).
 constexpr int kResWaves = 12;
 constexpr int kResThreads = 64 * kResWaves;
-constexpr int kResGatherWaves = 8;   // the gathering variant needs more registers per wave
+constexpr int kResGatherWaves = 8;   // the 128-column gathering variant needs more registers per wave
 constexpr int kResGatherThreads = 64 * kResGatherWaves;
 constexpr size_t kResMaxLds = 160 * 1024;
 
 template <int NT, int NKT, bool GATHER>
-__global__ __launch_bounds__(GATHER ? kResGatherThreads : kResThreads) void k_gemm_resident(GemmArgs g, int groups_per_sample, int wps, int gpw,
+__global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(GemmArgs g, int groups_per_sample, int wps, int gpw,
                                                                int batch) {
-  static_assert(!GATHER || (NT == 4 && NKT == 8), "the gathered segment is K tiles 4..7 of a 128-column launch");
-  constexpr int kWaves = GATHER ? kResGatherWaves : kResWaves;
+  static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
+  constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
+  constexpr int NX = GATHER ? NKT - 4 : NKT;   // K tiles read from the operand segments
   constexpr int BN = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) float res_smem[];
   // Weight image: for K tile kt, 8-row chunk c and column tile n, one 1 KiB piece in lane order:
@@ -525,22 +526,20 @@ __global__ __launch_bounds__(GATHER ? kResGatherThreads : kResThreads) void k_ge
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     if constexpr (GATHER) {
       load_table(grp);
-      load_tile(cur, 1, a1);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(0, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_tile(cur, 2, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(1, a1);
-      __builtin_amdgcn_sched_barrier(0);
-      load_tile(cur, 3, a1);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(2, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      gather_issue(0, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(3, a1);
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < NX; kt += 2) {
+        load_tile(cur, kt + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(kt, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < NX)
+          load_tile(cur, kt + 2, a0);
+        else
+          gather_issue(0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(kt + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         gather_reduce(q, a0, a1);
@@ -550,7 +549,7 @@ __global__ __launch_bounds__(GATHER ? kResGatherThreads : kResThreads) void k_ge
         else
           load_tile(nxt, 0, a0);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(4 + q, a1);
+        multiply(NX + q, a1);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -866,17 +865,21 @@ inline size_t resident_lds_bytes(int nt, int nkt) {   // weights + 2 KiB of stor
 }
 
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
-  if (g.row_map != nullptr || (nt != 3 && nt != 4)) return false;
+  if (g.row_map != nullptr) return false;
   for (int s = 0; s < g.n_seg; ++s)
     if (g.seg[s].k % kBK != 0) return false;
   const int kt = gemm_ktiles(g);
-  if (kt != 4 && kt != 8) return false;
+  if (g.gather_table != nullptr) {   // 128 columns x 8 K tiles, or 64 columns x 12 K tiles
+    if (!((nt == 4 && kt == 8) || (nt == 2 && kt == 12))) return false;
+  } else if ((nt != 3 && nt != 4) || (kt != 4 && kt != 8)) {
+    return false;
+  }
   if (resident_lds_bytes(nt, kt) > kResMaxLds) return false;
   for (int s = 0; s < g.n_seg; ++s)   // 32-bit byte offsets into every operand segment and the output
     if (batch * g.n_rows * g.seg[s].lda * 4 >= (int64_t{1} << 32)) return false;
   if (batch * (g.out_rows ? g.out_rows : g.n_rows) * g.ldo * 4 >= (int64_t{1} << 32)) return false;
-  if (g.gather_table != nullptr) {   // K tiles 4..7 of a 128-column launch, 32-bit offsets into the sources
-    if (nt != 4 || kt != 8 || g.n_seg < 2 || g.seg[g.n_seg - 1].k != 128) return false;
+  if (g.gather_table != nullptr) {   // the last segment is the gathered one; 32-bit offsets into the sources
+    if (g.n_seg < 2 || g.seg[g.n_seg - 1].k != 128) return false;
     for (int q = 0; q < 4; ++q)
       if (batch * g.gather_rows[q] * 128 >= (int64_t{1} << 32)) return false;
   }
@@ -900,10 +903,10 @@ struct ResidentSplit {
   int groups, wps, gpw;
 };
 
-inline ResidentSplit resident_split(int n_rows, int64_t batch, bool gather) {
+inline ResidentSplit resident_split(int n_rows, int64_t batch, int block_waves) {
   ResidentSplit r;
   r.groups = static_cast<int>(ceil_div(n_rows, kRowGroup));
-  const int64_t waves = static_cast<int64_t>(device_cu_count()) * (gather ? kResGatherWaves : kResWaves);
+  const int64_t waves = static_cast<int64_t>(device_cu_count()) * block_waves;
   const int per_sample = static_cast<int>(std::max<int64_t>(1, waves / batch));
   r.gpw = static_cast<int>(ceil_div(r.groups, std::min(per_sample, r.groups)));
   r.wps = static_cast<int>(ceil_div(r.groups, r.gpw));
@@ -920,7 +923,8 @@ inline bool takes_resident(const GemmArgs& g, int nt, int64_t batch, const void*
 // Rows of column-sum partials per sample that a launch writes (from colsum_tile0 on).
 inline int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
   if (g.n_rows == 0) return 0;
-  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, g.gather_table != nullptr).wps;
+  if (takes_resident(g, nt, batch, wpack))
+    return resident_split(g.n_rows, batch, (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves).wps;
   return static_cast<int>(ceil_div(g.n_rows, kRowGroup));
 }
 
@@ -936,8 +940,8 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResMaxLds)));
     raised[dev] = true;
   }
-  constexpr int kWaves = GATHER ? kResGatherWaves : kResWaves;
-  const ResidentSplit sp = resident_split(g.n_rows, batch, GATHER);
+  constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
+  const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
   const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kWaves));
   k_gemm_resident<NT, NKT, GATHER><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw, static_cast<int>(batch));
   GUNET_LAUNCH_CHECK();
@@ -946,7 +950,8 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
 
 int launch_gemm_resident(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
   const int kt = gemm_ktiles(g);
-  if (g.gather_table != nullptr) return launch_resident_inst<4, 8, true>(g, batch, stream);
+  if (g.gather_table != nullptr)
+    return nt == 4 ? launch_resident_inst<4, 8, true>(g, batch, stream) : launch_resident_inst<2, 12, true>(g, batch, stream);
   if (nt == 4) return kt == 4 ? launch_resident_inst<4, 4>(g, batch, stream) : launch_resident_inst<4, 8>(g, batch, stream);
   return kt == 4 ? launch_resident_inst<3, 4>(g, batch, stream) : launch_resident_inst<3, 8>(g, batch, stream);
 }
@@ -968,7 +973,10 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
   const bool split = takes_split(wpack), resident = !split && resident_ok(g, nt, batch);
   double flops = 0.0;
   for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
-  ProfScope prof(split ? kProfGemmSplit : (!resident ? kProfGemmTiled : (gemm_ktiles(g) == 4 ? kProfGemmRes128 : kProfGemmRes256)),
+  const int kt_all = gemm_ktiles(g);
+  ProfScope prof(split ? kProfGemmSplit
+                       : (!resident ? kProfGemmTiled
+                                    : (kt_all == 4 ? kProfGemmRes128 : (kt_all == 8 ? kProfGemmRes256 : kProfGemmRes384))),
                  stream, flops);
   if (split) {
     const int pieces = mode_pieces(g_matmul_mode);
@@ -1670,11 +1678,11 @@ int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const flo
 // GEMM with U output columns as U/128 launches of 128 columns.  `w_of(s, col)` gives the weight
 // pointer of segment s for the 32-column tile starting at output column `col`.
 template <typename WeightOf>
-GemmArgs columns_block(const GemmArgs& g, int units, int col0, const float* bias, int bias_stride, float* out,
+GemmArgs columns_block(const GemmArgs& g, int units, int col0, int nt, const float* bias, int bias_stride, float* out,
                        float* colsum, WeightOf w_of) {
   GemmArgs gc = g;
   for (int s = 0; s < g.n_seg; ++s)
-    for (int t = 0; t < 4; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
+    for (int t = 0; t < nt; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
   gc.bias = bias ? bias + col0 : nullptr;
   gc.bias_stride = bias_stride;
   gc.out = out;
@@ -1685,18 +1693,23 @@ GemmArgs columns_block(const GemmArgs& g, int units, int col0, const float* bias
   return gc;
 }
 
+// Column tiles per launch: 128 columns, except 64 for the gathering GEMM with three operand
+// segments (its weights fill LDS at that width).
+inline int columns_nt(const GemmArgs& g) { return (g.gather_table != nullptr && gemm_ktiles(g) == 12) ? 2 : 4; }
+
 // Column-sum partial rows per sample such a GEMM writes (the same for each of its column blocks).
 inline int columns_colsum_rows(const GemmArgs& g, int units, int64_t batch, const void* wpack) {
   GemmArgs gc = g;
   gc.ldo = units;
-  return gemm_colsum_rows(gc, 4, batch, wpack);
+  return gemm_colsum_rows(gc, columns_nt(g), batch, wpack);
 }
 
 template <typename WeightOf>
 int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
                         float* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
-  for (int col0 = 0; col0 < units; col0 += 128)
-    GUNET_TRY(launch_gemm(columns_block(g, units, col0, bias, bias_stride, out, colsum, w_of), 4, batch, wpack, stream));
+  const int nt = columns_nt(g);
+  for (int col0 = 0; col0 < units; col0 += 32 * nt)
+    GUNET_TRY(launch_gemm(columns_block(g, units, col0, nt, bias, bias_stride, out, colsum, w_of), nt, batch, wpack, stream));
   return GUNET_OK;
 }
 
@@ -1909,12 +1922,13 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
     gg.seg[g.n_seg - 1].lda = 0;
     gg.gather_table = graph->in_table;
     for (int q = 0; q < 4; ++q) {
-      gg.gather_src[q] = edges_out[q];
+      // an empty quadrant has only -1 table entries, whose (masked) loads still need a valid address
+      gg.gather_src[q] = graph->n_edges[q] > 0 ? edges_out[q] : x;
       gg.gather_rows[q] = graph->n_edges[q];
     }
     gg.gather_scale = 1.0f / (3 + 1);
     gg.ldo = U;
-    if (takes_resident(gg, 4, batch, ws.wpack)) {
+    if (takes_resident(gg, columns_nt(gg), batch, ws.wpack)) {
       g = gg;
       fused = true;
     }

@@ -342,3 +342,35 @@ def test_in_edge_table(amd, oracle):
         for v in range(node_loc.shape[0]):
             want = np.flatnonzero(recv == v)
             assert list(table[v, q, :want.size]) == list(want) and (table[v, q, want.size:] == -1).all()
+
+
+def test_gn_layer_fused_aggregation_edge_cases(amd, oracle):
+    """The message-summing node MLP on a grid graph with one quadrant emptied and a skip segment
+    (three operand segments), single sample and batched."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(29, 37, 0.55, 17)
+    quads = list(oracle.sample_quadrant_subgraphs(ei, d))
+    quads[2] = quads[2][:0]
+    rng = np.random.Generator(np.random.PCG64(18))
+    n = node_loc.shape[0]
+    x = (rng.random((n, 256)) - 0.3).astype(np.float32)
+    graph = {'edge_index': quads, 'node_loc': node_loc,
+             'edges': [rng.random((q.shape[0], 16)).astype(np.float32) for q in quads],
+             'global': rng.random((1, 128)).astype(np.float32)}
+    W = _layer_weights(oracle, 'L', 256, 16, 128)
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
+    layer = amd.hybrid_gnn.GeoQuadrantGCN(128, activation='relu', use_bias=True, use_global=True)
+    layer.load_weights(W, 'L', 'cuda')
+    g = graph_to_dev(graph)
+    assert amd.plan.get_quadgraph(g['edge_index'], n).in_table is not None
+    xt = to_dev(x)
+    got_x, got_g = layer._forward(xt[:, :128].contiguous(), g, x_skip=xt[:, 128:].contiguous())
+    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    g2 = graph_to_dev(graph)
+    g2['edge_index'] = g['edge_index']
+    g2['edges'] = [e.unsqueeze(0).repeat(3, 1, 1) for e in g2['edges']]
+    g2['global'] = g2['global'].repeat(3, 1)
+    bx, bg = layer._forward(xt[:, :128].contiguous().unsqueeze(0).repeat(3, 1, 1), g2,
+                            x_skip=xt[:, 128:].contiguous().unsqueeze(0).repeat(3, 1, 1))
+    for b in range(3):
+        assert torch.equal(bx[b], got_x) and torch.equal(bg['global'][b], got_g['global'][0])
