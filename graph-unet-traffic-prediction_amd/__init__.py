@@ -8,7 +8,7 @@ Layout mirrors the reference modules that lie on the path:
     models.graph_unet   GraphUNet
 """
 from . import _lib                                   # raises if libgunet_hip.so is missing
-from ._lib import GunetError, LIB_PATH, set_matmul_mode, get_matmul_mode
+from ._lib import GunetError, LIB_PATH, set_matmul_mode, get_matmul_mode, set_kernel_choice
 from . import plan
 from . import layers
 from .layers import hybrid_gnn, graph_ops

@@ -78,6 +78,7 @@ SIGNATURES = {
                                         C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     'gunet_set_matmul_mode': (C.c_int, [C.c_int]),
     'gunet_get_matmul_mode': (C.c_int, []),
+    'gunet_set_kernel_choice': (C.c_int, [C.c_int]),
     'gunet_dense_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'gunet_dense_forward_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -182,3 +183,12 @@ def set_matmul_mode(mode):
 def get_matmul_mode():
     code = lib.gunet_get_matmul_mode()
     return {v: k for k, v in MATMUL_MODES.items()}[code]
+
+
+KERNEL_CHOICES = {'auto': 0, 'resident': 1, 'tiled': 2}
+
+
+def set_kernel_choice(choice):
+    """'auto' (default), 'resident' (weights-resident / message-summing GEMMs wherever they apply) or
+    'tiled' (never): a tuning and test knob, results agree to rounding."""
+    call('gunet_set_kernel_choice', KERNEL_CHOICES[choice] if isinstance(choice, str) else int(choice))

@@ -819,8 +819,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
   }
 }
 
-// Matmul arithmetic of the feature kernels (gunet_set_matmul_mode).
+// Matmul arithmetic of the feature kernels (gunet_set_matmul_mode) and the GEMM kernel choice
+// (gunet_set_kernel_choice).
 int g_matmul_mode = GUNET_MATMUL_F32;
+int g_kernel_choice = GUNET_KERNELS_AUTO;
 
 inline int mode_pieces(int mode) {
   return mode == GUNET_MATMUL_SPLIT3 ? 3 : mode == GUNET_MATMUL_SPLIT2 ? 2 : mode == GUNET_MATMUL_BF16 ? 1 : 0;
@@ -858,6 +860,18 @@ int launch_gemm_split(const GemmArgs& g, int nt, dim3 grid, uint4* wpack, hipStr
   return GUNET_OK;
 }
 
+inline int device_cu_count() {
+  static int n_cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (n_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n_cus[dev] = n;
+  }
+  return n_cus[dev];
+}
+
 // The weights-resident kernel takes launches whose operand segments are whole K tiles adding up to
 // 128 or 256, with 96 or 128 output columns and identity row mapping.
 inline size_t resident_lds_bytes(int nt, int nkt) {   // weights + 2 KiB of store staging per wave
@@ -878,24 +892,21 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   for (int s = 0; s < g.n_seg; ++s)   // 32-bit byte offsets into every operand segment and the output
     if (batch * g.n_rows * g.seg[s].lda * 4 >= (int64_t{1} << 32)) return false;
   if (batch * (g.out_rows ? g.out_rows : g.n_rows) * g.ldo * 4 >= (int64_t{1} << 32)) return false;
+  // Below about two row groups per wave the one-off copy of the weights into every workgroup's LDS
+  // costs more than the tiled kernel's barriers (measured crossover near 200 k rows); the gathering
+  // form also saves the aggregation pass, which moves its break-even down to half a group per wave.
+  if (g_kernel_choice == GUNET_KERNELS_TILED) return false;
+  if (g_kernel_choice == GUNET_KERNELS_AUTO) {
+    const int64_t groups = batch * ceil_div(g.n_rows, kRowGroup);
+    const int64_t waves = static_cast<int64_t>(device_cu_count()) * kResWaves;
+    if (g.gather_table == nullptr ? groups < 2 * waves : 2 * groups < waves) return false;
+  }
   if (g.gather_table != nullptr) {   // the last segment is the gathered one; 32-bit offsets into the sources
     if (g.n_seg < 2 || g.seg[g.n_seg - 1].k != 128) return false;
     for (int q = 0; q < 4; ++q)
       if (batch * g.gather_rows[q] * 128 >= (int64_t{1} << 32)) return false;
   }
   return batch * ceil_div(g.n_rows, kRowGroup) < (1 << 30);
-}
-
-inline int device_cu_count() {
-  static int n_cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (n_cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    n_cus[dev] = n;
-  }
-  return n_cus[dev];
 }
 
 // Work split of the resident kernel: every sample's row groups in runs of gpw, wps waves per sample.
@@ -1824,6 +1835,13 @@ int gunet_set_matmul_mode(int mode) {
 }
 
 int gunet_get_matmul_mode(void) { return g_matmul_mode; }
+
+int gunet_set_kernel_choice(int choice) {
+  GUNET_REQUIRE(choice == GUNET_KERNELS_AUTO || choice == GUNET_KERNELS_RESIDENT || choice == GUNET_KERNELS_TILED,
+                "set_kernel_choice: unknown choice %d", choice);
+  g_kernel_choice = choice;
+  return GUNET_OK;
+}
 
 size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batch, int32_t units) {
   if (graph == nullptr || batch <= 0 || (units != 128 && units != 256)) return 0;

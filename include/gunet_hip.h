@@ -134,6 +134,16 @@ int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const 
 int gunet_set_matmul_mode(int mode);
 int gunet_get_matmul_mode(void);
 
+/* Which float32 GEMM kernel the feature functions take (no counterpart in the reference; results
+ * agree to rounding).  AUTO (default): the weights-resident kernels -- including the node MLP that
+ * sums the messages while loading them -- where they apply and the launch is large enough to pay
+ * for copying the weights into every workgroup, else the tiled kernel.  RESIDENT: wherever they
+ * apply, whatever the size.  TILED: never (a separate aggregation pass feeds the node MLP). */
+#define GUNET_KERNELS_AUTO 0
+#define GUNET_KERNELS_RESIDENT 1
+#define GUNET_KERNELS_TILED 2
+int gunet_set_kernel_choice(int choice);
+
 /* tf.keras.layers.Dense (models/graph_unet.py:37,58,66,82): out = act(x @ kernel + bias).
  * x [rows, k]; kernel [k, n_out]; bias [n_out] or NULL; out [rows, n_out].
  * workspace: gunet_dense_workspace_bytes(k, n_out) bytes, 16-byte aligned; may be NULL in

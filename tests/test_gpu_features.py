@@ -344,7 +344,32 @@ def test_in_edge_table(amd, oracle):
             assert list(table[v, q, :want.size]) == list(want) and (table[v, q, want.size:] == -1).all()
 
 
-def test_gn_layer_fused_aggregation_edge_cases(amd, oracle):
+@pytest.fixture
+def resident_kernels(amd):
+    """Take the weights-resident / message-summing GEMMs whatever the size (small test graphs would
+    otherwise get the tiled kernel)."""
+    amd.set_kernel_choice('resident')
+    yield
+    amd.set_kernel_choice('auto')
+
+
+@pytest.mark.parametrize('choice', ['resident', 'tiled'])
+def test_graph_unet_kernel_choices(amd, oracle, choice):
+    """The whole model with every GEMM forced onto one kernel family."""
+    x, graph, _ = make_case(oracle, 40, 52, 0.45)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    amd.set_kernel_choice(choice)
+    try:
+        got_y, got_g = _unet(amd, oracle, W)(to_dev(x), graph_to_dev(graph))
+        got_y, got_glob = got_y.cpu().numpy(), got_g['global'].cpu().numpy()
+    finally:
+        amd.set_kernel_choice('auto')
+    assert rel_err(got_y, want_y) <= TOL
+    assert rel_err(got_glob, want_g['global']) <= TOL
+
+
+def test_gn_layer_fused_aggregation_edge_cases(amd, oracle, resident_kernels):
     """The message-summing node MLP on a grid graph with one quadrant emptied and a skip segment
     (three operand segments), single sample and batched."""
     node_loc, ei, d, _ = oracle.synth_road_graph(29, 37, 0.55, 17)

@@ -28,7 +28,7 @@ def gemm():
     dev = torch.device('cuda')
     if os.environ.get('GUNET_MODE'):
         gunet_amd.set_matmul_mode(os.environ['GUNET_MODE'])
-    rows = 96493 * 8
+    rows = int(os.environ.get('GUNET_ROWS', 96493 * 8))
     for k, n in [(128, 128), (256, 128), (384, 128), (104, 128), (128, 96)]:
         x = torch.rand((rows, k), device=dev)
         w = torch.rand((k, n), device=dev) - 0.5
@@ -37,7 +37,7 @@ def gemm():
         st = current_stream(dev)
         wsb = torch.empty(gunet_amd._lib.lib.gunet_dense_workspace_bytes(k, n), dtype=torch.uint8, device=dev)
         fn = lambda: call('gunet_dense_forward_f32', ptr(x), rows, k, ptr(w), ptr(b), n, 1, ptr(out), ptr(wsb), wsb.numel(), st)
-        ms = time_ms(fn)
+        ms = time_ms(fn, iters=int(os.environ.get('GUNET_ITERS', 10)))
         ref = torch.relu(x[:4096].double() @ w.double() + b.double())
         fn()
         err = float((out[:4096].double() - ref).abs().max() / ref.abs().max())
