@@ -139,9 +139,9 @@ struct GemmArgs {
   const int32_t* row_map;     // A row r -> output row row_map[r * row_map_stride] - row_map_sub
   int row_map_stride;         //   (null = identity)
   int row_map_sub;
-  float* colsum;              // column sums of the activated output per group of 32 rows, or null:
-  int colsum_tiles;           //   [B][colsum_tiles][colsum_ld], this launch fills groups
-  int colsum_tile0;           //   colsum_tile0 .. colsum_tile0 + ceil(n_rows / 32) - 1
+  float* colsum;              // partial column sums of the activated output, or null:
+  int colsum_tiles;           //   [B][colsum_tiles][colsum_ld], this launch fills rows colsum_tile0 ..
+  int colsum_tile0;           //   colsum_tile0 + gemm_colsum_rows() - 1 (one per workgroup or per wave)
   int colsum_ld;              //   floats (0 = 32*NT), this launch's columns start at out_col0
   int relu;
   // Gathered last segment (weights-resident kernel only): when gather_table is set, the last
@@ -315,12 +315,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
       }
     }
   }
-  if (g.colsum != nullptr && wrow0 < g.n_rows) {
-    float* dst = g.colsum + (b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x * 4 + wave) * g.colsum_ld + g.out_col0 + li;
+  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' sums added in order
+    float* red = Stage[0];     // 4 * BN <= 512 floats; the staging tiles are no longer in use
+    __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) dst[32 * n] = cs[n];
+      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
 }
@@ -809,12 +815,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
       }
     }
   }
-  if (g.colsum != nullptr && row0 + 32 * wave < g.n_rows) {
-    float* dst = g.colsum + (b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x * 4 + wave) * g.colsum_ld + g.out_col0 + li;
+  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' sums added in order
+    __shared__ float red[4 * BN];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) dst[32 * n] = cs[n];
+      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
 }
@@ -936,7 +947,7 @@ inline int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void
   if (g.n_rows == 0) return 0;
   if (takes_resident(g, nt, batch, wpack))
     return resident_split(g.n_rows, batch, (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves).wps;
-  return static_cast<int>(ceil_div(g.n_rows, kRowGroup));
+  return static_cast<int>(ceil_div(g.n_rows, kBM));
 }
 
 template <int NT, int NKT, bool GATHER = false>
