@@ -302,15 +302,23 @@ def main():
             result['gemm_all'] = {'ms_per_step': gemm_ms / steps, 'launches_per_step': sum(prof[k][1] for k in GEMM_CLASSES) / steps,
                                   'executed_tflops': gemm_flops / (gemm_ms * 1e-3) / 1e12,
                                   'as_written_tflops': B * work['gemm_flops'] * steps / (gemm_ms * 1e-3) / 1e12}
-        if agg_n:
-            agg_gbps = agg_bytes / (agg_ms * 1e-3) / 1e9
-            gs_gbps = B * (work['aggregate_bytes'] + work['gather_bytes']) * steps / ((agg_ms + edge_ms) * 1e-3) / 1e9
-            result['gather_scatter'] = {
-                'aggregate_GBps': agg_gbps, 'aggregate_frac_of_hbm_peak': agg_gbps / workload.PEAK_HBM_GBPS,
-                'aggregate_avg_launch_ms': agg_ms / agg_n,
-                'gather_plus_aggregate_logical_GBps': gs_gbps,
-                'note': 'k_aggregate: 4(Eu+E+NU) B per launch it runs; logical figure: gathers 4(2Eu+2E) (fused into the '
-                        'edge-MLP kernel) + segment-sum bytes of all 14 layers over edge-MLP + aggregate time'}
+        if edge_n:
+            # gathers 4(2Eu+2E) happen inside the edge-MLP kernel; the segment sum 4(Eu+E+NU) is either
+            # k_aggregate or, for layers whose node MLP sums the messages while loading them
+            # (k_gemm_resident<.., true>), costs no pass of its own
+            logical = B * (work['aggregate_bytes'] + work['gather_bytes']) * steps
+            gs = {'gather_plus_segment_sum_logical_GBps': logical / ((agg_ms + edge_ms) * 1e-3) / 1e9,
+                  'edge_mlp_avg_launch_ms': edge_ms / edge_n, 'aggregate_launches_per_step': agg_n / steps,
+                  'note': 'logical bytes of all 14 layers (gathers 4(2Eu+2E) + segment sum 4(Eu+E+NU)) over the time of '
+                          'the kernels that do nothing else (edge MLP incl. its matrix work, k_aggregate where it still '
+                          'runs); the segment sum of the other layers is part of the node-MLP GEMM'}
+            if agg_n:
+                gs['aggregate_GBps'] = agg_bytes / (agg_ms * 1e-3) / 1e9
+            edge_traffic = measured_traffic('k_edge_mlp', args)
+            if edge_traffic is not None:
+                gs['edge_mlp_measured_hbm_GBps'] = edge_traffic['bytes_per_launch'] / (edge_ms / edge_n * 1e-3) / 1e9
+                gs['edge_mlp_frac_of_hbm_peak'] = gs['edge_mlp_measured_hbm_GBps'] / workload.PEAK_HBM_GBPS
+            result['gather_scatter'] = gs
         mfma_ms = gemm_ms + edge_ms
         if mfma_ms > 0:
             tf = (gemm_flops + edge_flops) / (mfma_ms * 1e-3) / 1e12
