@@ -171,7 +171,6 @@ def main():
     if world > 1 and rank == 0:
         gathered = [torch.empty((world,) + tuple(y.shape), dtype=y.dtype, device=dev) for _ in range(2)]
     pending = [None, None]
-    metrics = torch.zeros(2, dtype=torch.float64, device=dev)
 
     def step(i):
         y = forward()
@@ -190,7 +189,6 @@ def main():
             else:
                 works.append(dist.gather(out_bufs[slot], gather_list=None, dst=0, async_op=True))
             pending[slot] = works
-            metrics.copy_(m)
         return y
 
     def drain():

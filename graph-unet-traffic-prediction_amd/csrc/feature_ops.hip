@@ -331,8 +331,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
   }
 }
 
-// Weights-resident variant for 32 * NKT <= 256 total K: a workgroup of twelve waves copies the
-// whole weight matrix into LDS once, then its waves work on their own, with no barrier after the
+// Weights-resident variant (the weight matrix must fit LDS: 32 * NKT * 32 * NT floats): a workgroup
+// of twelve waves (eight for the 128-column gathering form) copies the whole weight matrix into
+// LDS once, then its waves work on their own, with no barrier after the
 // first: every sample's 32-row groups are dealt out in runs of `gpw` consecutive groups, one run
 // per wave (`wps` waves per sample).  The A tile of step t+1 -- the next group's first tile at a
 // group's last step -- is requested before the MFMAs of step t, into the other of two register
