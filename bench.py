@@ -166,37 +166,16 @@ def main():
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - t0) * 1e3
 
-    out_bufs = [torch.empty_like(y) for _ in range(2)]
-    gathered = [None, None]
-    if world > 1 and rank == 0:
-        gathered = [torch.empty((world,) + tuple(y.shape), dtype=y.dtype, device=dev) for _ in range(2)]
-    pending = [None, None]
+    exchange = sharding.StepExchange(y)
 
     def step(i):
         y = forward()
         if world > 1:
-            slot = i & 1
-            if pending[slot] is not None:
-                for w in pending[slot]:
-                    w.wait()
-            out_bufs[slot].copy_(y)
-            m = torch.stack((out_bufs[slot].sum(dtype=torch.float64),
-                             torch.tensor(float(y.shape[0]), dtype=torch.float64, device=dev)))
-            works = [dist.all_reduce(m, async_op=True)]
-            if rank == 0:
-                works.append(dist.gather(out_bufs[slot], gather_list=list(gathered[slot].unbind(0)), dst=0,
-                                         async_op=True))
-            else:
-                works.append(dist.gather(out_bufs[slot], gather_list=None, dst=0, async_op=True))
-            pending[slot] = works
+            m = torch.stack((y.sum(dtype=torch.float64), torch.tensor(float(y.shape[0]), dtype=torch.float64, device=dev)))
+            exchange.post(i, y, m)
         return y
 
-    def drain():
-        for slot in range(2):
-            if pending[slot] is not None:
-                for w in pending[slot]:
-                    w.wait()
-                pending[slot] = None
+    drain = exchange.drain
 
     for i in range(args.warmup):
         y = step(i)

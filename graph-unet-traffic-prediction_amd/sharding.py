@@ -69,3 +69,45 @@ def sum_metrics(values, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(values, group=group)
     return values
+
+
+class StepExchange:
+    """What a multi-GPU run exchanges per step: the predictions of every rank gathered on rank 0 and
+    a small metrics vector summed over the ranks.  Both are posted asynchronously and double-buffered
+    (step i uses slot i & 1 and first waits for step i - 2 in that slot), so the transfers of one
+    step overlap the forward of the next.  With one rank nothing is posted."""
+
+    def __init__(self, like, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.out = [torch.empty_like(like) for _ in range(2)] if self.world > 1 else None
+        self.gathered = [None, None]
+        if self.world > 1 and self.rank == 0:
+            self.gathered = [torch.empty((self.world,) + tuple(like.shape), dtype=like.dtype, device=like.device)
+                             for _ in range(2)]
+        self.metrics = [None, None]
+        self.pending = [None, None]
+
+    def post(self, step, y, metrics):
+        """y: this rank's predictions (same shape on every rank); metrics: 1-D float64 numerators."""
+        if self.world == 1:
+            return
+        slot = step & 1
+        self.wait(slot)
+        self.out[slot].copy_(y)
+        self.metrics[slot] = metrics
+        works = [dist.all_reduce(metrics, group=self.group, async_op=True)]
+        gather_list = list(self.gathered[slot].unbind(0)) if self.rank == 0 else None
+        works.append(dist.gather(self.out[slot], gather_list=gather_list, dst=0, group=self.group, async_op=True))
+        self.pending[slot] = works
+
+    def wait(self, slot):
+        if self.pending[slot] is not None:
+            for w in self.pending[slot]:
+                w.wait()
+            self.pending[slot] = None
+
+    def drain(self):
+        self.wait(0)
+        self.wait(1)

@@ -37,6 +37,18 @@ def _worker(rank, world, port, out_dir):
     else:
         assert gathered is None and eq is None
     np.save(os.path.join(out_dir, f'mine{rank}.npy'), np.array(mine))
+    # the per-step exchange of the benchmark: 5 steps, double-buffered, checked after draining
+    ex = sharding.StepExchange(torch.zeros((3, 4)))
+    for i in range(5):
+        y = torch.full((3, 4), float(10 * i + rank))
+        ex.post(i, y, torch.tensor([float(i), float(rank)], dtype=torch.float64))
+    ex.drain()
+    if rank == 0:
+        for i in (3, 4):                                               # the last two steps are still in the slots
+            want = torch.stack([torch.full((3, 4), float(10 * i + r)) for r in range(world)])
+            assert torch.equal(ex.gathered[i & 1], want), i
+    for i in (3, 4):
+        assert ex.metrics[i & 1].tolist() == [float(i * world), float(sum(range(world)))]
     dist.barrier()
     dist.destroy_process_group()
 
