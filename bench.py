@@ -39,16 +39,18 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-runs', type=int, default=3)
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel event pass')
+    ap.add_argument('--no-alt-modes', action='store_true', help='skip the short bf16-operand run reported beside the result')
     ap.add_argument('--matmul', default=os.environ.get('GUNET_BENCH_MATMUL', 'f32'), choices=['f32', 'split3', 'split2', 'bf16'],
                     help='matrix-product arithmetic (see gunet_set_matmul_mode)')
     return ap.parse_args()
 
 
-GEMM_CLASSES = ('gemm_tiled', 'gemm_resident_k128', 'gemm_resident_k256', 'gemm_resident_k384', 'gemm_split')
+GEMM_CLASSES = ('gemm_tiled', 'gemm_resident_k128', 'gemm_resident_k256', 'gemm_resident_k384', 'gemm_resident_bf16',
+                'gemm_split')
 MFMA_CLASSES = GEMM_CLASSES + ('edge_mlp',)
 KERNEL_OF_CLASS = {'gemm_tiled': 'k_gemm_f32', 'gemm_resident_k128': 'k_gemm_resident<*, 4>',
                    'gemm_resident_k256': 'k_gemm_resident<*, 8>', 'gemm_resident_k384': 'k_gemm_resident<*, 12>',
-                   'gemm_split': 'k_gemm_split', 'edge_mlp': 'k_edge_mlp',
+                   'gemm_resident_bf16': 'k_gemm_resident<.., bf16>', 'gemm_split': 'k_gemm_split', 'edge_mlp': 'k_edge_mlp',
                    'aggregate': 'k_aggregate', 'segment_reduce': 'k_segment_reduce', 'layer_prologue': 'k_layer_prologue',
                    'global_update': 'k_global_update', 'gather_rows': 'k_gather_rows', 'dense_naive': 'k_dense_naive'}
 
@@ -210,6 +212,26 @@ def main():
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
 
+    # ---- the bf16-operand mode (float32 storage and accumulation), reported beside the result --------
+    alt = None
+    if world == 1 and args.matmul == 'f32' and not args.no_alt_modes:
+        gunet_amd.set_matmul_mode('bf16')
+        try:
+            for _ in range(2):
+                y_alt = forward()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                y_alt = forward()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            alt = {'bf16': {'value': B * 10 / dt, 'unit': 'samples/s', 'ms_per_step': dt / 10 * 1e3, 'steps': 10,
+                            'rel_diff_vs_f32_run': float((y_alt - y).abs().max() / y.abs().max()),
+                            'note': 'same workload with gunet_set_matmul_mode(GUNET_MATMUL_BF16): GEMM operands rounded to '
+                                    'bf16 for v_mfma_f32_32x32x16_bf16, float32 accumulate and storage; tolerance 2e-2'}}
+        finally:
+            gunet_amd.set_matmul_mode('f32')
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -302,6 +324,8 @@ def main():
             result['mfma_utilisation'] = {'executed_tflops_over_gemm_and_edge_kernels': tf,
                                           'frac_of_f32_peak': tf / workload.PEAK_F32_MFMA_TFLOPS,
                                           'as_written_tflops': B * work['total_flops'] * steps / (mfma_ms * 1e-3) / 1e12}
+    if alt is not None:
+        result['alt_matmul_modes'] = alt
     if world == 1 and not args.no_cpu_baseline:
         base, y_cpu = cpu_baseline(args, (node_loc, quads_np), weights, first)
         result['cpu_baseline'] = base

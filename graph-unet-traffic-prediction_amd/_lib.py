@@ -49,7 +49,7 @@ class GnWeightsStruct(C.Structure):
 
 VoidP4 = C.c_void_p * 4
 I64x4 = C.c_int64 * 4
-PROF_CLASSES = 12
+PROF_CLASSES = 13
 F64xP = C.c_double * PROF_CLASSES
 I64xP = C.c_int64 * PROF_CLASSES
 

@@ -81,6 +81,7 @@ enum ProfClass {
   kProfGemmRes256,
   kProfGemmSplit,
   kProfGemmRes384,
+  kProfGemmResBf16,
   kProfCount
 };
 static_assert(kProfCount == GUNET_PROF_CLASSES, "profiler class table out of step with the header");

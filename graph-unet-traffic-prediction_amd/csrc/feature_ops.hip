@@ -15,6 +15,7 @@ namespace gunet {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
 
@@ -346,9 +347,13 @@ constexpr int kResGatherWaves = 8;   // the 128-column gathering variant needs m
 constexpr int kResGatherThreads = 64 * kResGatherWaves;
 constexpr size_t kResMaxLds = 160 * 1024;
 
-template <int NT, int NKT, bool GATHER>
-__global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(GemmArgs g, int groups_per_sample, int wps, int gpw,
-                                                               int batch) {
+// BF16 = true: operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16 (float32
+// accumulate and storage); a lane then owns, per 16-wide k step, 8 consecutive floats of its row
+// (k = 16s + 8 * lh + 0..7), and the LDS weight image holds one bf16x8 per lane, k step and column
+// tile.  The matrix work shrinks 16-fold, so this form runs at the speed of its memory traffic.
+template <int NT, int NKT, bool GATHER, bool BF16>
+__global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(
+    GemmArgs g, int groups_per_sample, int wps, int gpw, int batch) {
   static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   constexpr int NX = GATHER ? NKT - 4 : NKT;   // K tiles read from the operand segments
@@ -369,15 +374,28 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float* w = sg.w[t];
-        for (int i = tid; i < sg.k * 8; i += kWaves * 64) {
-          const int row = kbase + (i >> 3), c4 = i & 7;
-          const float4 v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
-          // row = 8 * chunk + 4 * half + j
-          float* dst = Ws + (((row >> 3) * NT + t) * 64 + ((row >> 2) & 1) * 32 + 4 * c4) * 4 + (row & 3);
-          dst[0] = v.x;
-          dst[4] = v.y;
-          dst[8] = v.z;
-          dst[12] = v.w;
+        if constexpr (BF16) {
+          // thread -> (group of 8 k rows, column): 8 strided loads, one 16-byte LDS store
+          uint4* img = reinterpret_cast<uint4*>(Ws);
+          for (int i = tid; i < sg.k * 4; i += kWaves * 64) {
+            const int kg = i >> 5, col = i & 31;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = static_cast<__bf16>(w[static_cast<int64_t>(8 * kg + j) * sg.ldw + col]);
+            const int k0 = kbase + 8 * kg;   // = 16 * kstep + 8 * half
+            img[((k0 >> 4) * NT + t) * 64 + ((k0 >> 3) & 1) * 32 + col] = __builtin_bit_cast(uint4, v);
+          }
+        } else {
+          for (int i = tid; i < sg.k * 8; i += kWaves * 64) {
+            const int row = kbase + (i >> 3), c4 = i & 7;
+            const float4 v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
+            // row = 8 * chunk + 4 * half + j
+            float* dst = Ws + (((row >> 3) * NT + t) * 64 + ((row >> 2) & 1) * 32 + 4 * c4) * 4 + (row & 3);
+            dst[0] = v.x;
+            dst[4] = v.y;
+            dst[8] = v.z;
+            dst[12] = v.w;
+          }
         }
       }
       kbase += sg.k;
@@ -398,6 +416,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     row = row < g.n_rows ? row : g.n_rows - 1;
     return static_cast<uint32_t>(b) * static_cast<uint32_t>(g.n_rows) + static_cast<uint32_t>(row);
   };
+  // The four 16-byte pieces a lane reads of a 32-float K tile: floats 8c + 4lh + 0..3 (c = 0..3)
+  // for the float32 MFMA, floats 16s + 8lh + 4i + 0..3 (s, i = 0, 1) for the bf16 one.
+  constexpr uint32_t kLaneFloats = BF16 ? 8u : 4u;
+  auto chunk_bytes = [](int c) -> uint32_t { return BF16 ? 64u * (c >> 1) + 16u * (c & 1) : 32u * c; };
   // uniform base pointer + 32-bit per-lane byte offset (the host checks that every operand
   // segment and the output are smaller than 4 GiB)
   auto load_tile = [&](uint32_t arow, int kt, float4 (&a)[4]) {
@@ -406,28 +428,44 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     const float* base = s == 0 ? g.seg[0].a : (s == 1 ? g.seg[1].a : g.seg[2].a);
     const uint32_t lda = static_cast<uint32_t>(s == 0 ? g.seg[0].lda : (s == 1 ? g.seg[1].lda : g.seg[2].lda));
     const char* sb = reinterpret_cast<const char*>(base + k0);
-    const uint32_t voff = (arow * lda + 4u * static_cast<uint32_t>(lh)) * 4u;
+    const uint32_t voff = (arow * lda + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const float4*>(sb + voff + 32u * c);
+    for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const float4*>(sb + voff + chunk_bytes(c));
   };
 
   f32x16 acc[NT];
   const float4* wl = reinterpret_cast<const float4*>(Ws) + lane;
   auto multiply = [&](int kt, const float4 (&a)[4]) {
+    if constexpr (BF16) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float4 w[NT];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 ap;
+        const float av[8] = {a[2 * s2].x,     a[2 * s2].y,     a[2 * s2].z,     a[2 * s2].w,
+                             a[2 * s2 + 1].x, a[2 * s2 + 1].y, a[2 * s2 + 1].z, a[2 * s2 + 1].w};
 #pragma unroll
-      for (int n = 0; n < NT; ++n) w[n] = wl[((kt * 4 + c) * NT + n) * 64];
-      // the NT accumulators take turns, so no MFMA waits for the one before it
+        for (int j = 0; j < 8; ++j) ap[j] = static_cast<__bf16>(av[j]);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, w[n].x, acc[n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) {
+          const bf16x8 w = __builtin_bit_cast(bf16x8, wl[((2 * kt + s2) * NT + n) * 64]);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, w, acc[n], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, w[n].y, acc[n], 0, 0, 0);
+      for (int c = 0; c < 4; ++c) {
+        float4 w[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, w[n].z, acc[n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) w[n] = wl[((kt * 4 + c) * NT + n) * 64];
+        // the NT accumulators take turns, so no MFMA waits for the one before it
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, w[n].w, acc[n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, w[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, w[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, w[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, w[n].w, acc[n], 0, 0, 0);
+      }
     }
   };
   // Epilogue: bias, activation, column sums, and the tile's way to memory.  A lane holds one column
@@ -436,7 +474,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // up row-wise, so a store instruction writes eight full 128-byte lines (four floats per lane).
   const bool has_out = g.out != nullptr;
   const uint32_t ldo = static_cast<uint32_t>(g.ldo);
-  float* stage = res_smem + 32 * NKT * BN + wave * (16 * 32);
+  float* stage = res_smem + (BF16 ? 16 : 32) * NKT * BN + wave * (16 * 32);
   const int srow = lane >> 3, scol = 4 * (lane & 7);
   float bias_v[NT], cs[NT];
 #pragma unroll
@@ -498,10 +536,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int id = tab_at(3 * q + j);
-      const uint32_t voff = ((base + static_cast<uint32_t>(id > 0 ? id : 0)) * 32u + 4u * static_cast<uint32_t>(lh)) * 4u;
+      const uint32_t voff = ((base + static_cast<uint32_t>(id > 0 ? id : 0)) * 32u + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(sb + voff + 32u * c);
+        const float4 v = *reinterpret_cast<const float4*>(sb + voff + chunk_bytes(c));
         if (j < 2)
           gbuf[j][c] = v;
         else
@@ -625,7 +663,6 @@ __global__ void k_dense_naive(const float* __restrict__ x, int64_t rows, int k,
 // MFMA, so even the 6-term form needs 2.7x fewer matrix-core cycles than k_gemm_f32.
 // The weight pieces are prepared once per launch by k_pack_weights in the exact image the
 // workgroups copy into LDS: [k tile][piece][k step][half][column][8 consecutive k] bf16.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int SPL>
 struct Pieces {
@@ -884,23 +921,31 @@ inline int device_cu_count() {
   return n_cus[dev];
 }
 
-// The weights-resident kernel takes launches whose operand segments are whole K tiles adding up to
-// 128 or 256, with 96 or 128 output columns and identity row mapping.
-inline size_t resident_lds_bytes(int nt, int nkt) {   // weights + 2 KiB of store staging per wave
-  return sizeof(float) * (static_cast<size_t>(32 * nkt) * 32 * nt + static_cast<size_t>(kResWaves) * 16 * 32);
+// The weights-resident kernels take launches whose operand segments are whole K tiles, with
+// identity row mapping, when the weight image (float32, or bf16 in GUNET_MATMUL_BF16 mode) fits LDS
+// next to 2 KiB of store staging per wave.
+inline bool bf16_mode() { return g_matmul_mode == GUNET_MATMUL_BF16; }
+
+inline size_t resident_lds_bytes(int nt, int nkt, bool bf16) {
+  return (bf16 ? 2 : 4) * static_cast<size_t>(32 * nkt) * 32 * nt + sizeof(float) * kResWaves * 16 * 32;
 }
 
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   if (g.row_map != nullptr) return false;
+  if (mode_pieces(g_matmul_mode) > 1) return false;   // split-bf16 modes: tiled kernel only
+  const bool bf16 = bf16_mode();
   for (int s = 0; s < g.n_seg; ++s)
     if (g.seg[s].k % kBK != 0) return false;
   const int kt = gemm_ktiles(g);
-  if (g.gather_table != nullptr) {   // 128 columns x 8 K tiles, or 64 columns x 12 K tiles
+  if (bf16) {   // 96 or 128 columns, 4 / 8 / 12 K tiles; gathering form: 128 columns, 8 or 12 K tiles
+    if (g.gather_table != nullptr ? !(nt == 4 && (kt == 8 || kt == 12)) : !((nt == 3 || nt == 4) && (kt == 4 || kt == 8)))
+      return false;
+  } else if (g.gather_table != nullptr) {   // 128 columns x 8 K tiles, or 64 columns x 12 K tiles
     if (!((nt == 4 && kt == 8) || (nt == 2 && kt == 12))) return false;
   } else if ((nt != 3 && nt != 4) || (kt != 4 && kt != 8)) {
     return false;
   }
-  if (resident_lds_bytes(nt, kt) > kResMaxLds) return false;
+  if (resident_lds_bytes(nt, kt, bf16) > kResMaxLds) return false;
   for (int s = 0; s < g.n_seg; ++s)   // 32-bit byte offsets into every operand segment and the output
     if (batch * g.n_rows * g.seg[s].lda * 4 >= (int64_t{1} << 32)) return false;
   if (batch * (g.out_rows ? g.out_rows : g.n_rows) * g.ldo * 4 >= (int64_t{1} << 32)) return false;
@@ -921,6 +966,11 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   return batch * ceil_div(g.n_rows, kRowGroup) < (1 << 30);
 }
 
+// Waves per workgroup of the resident kernel a launch gets.
+inline int resident_block_waves(const GemmArgs& g, int nt) {
+  return (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves;
+}
+
 // Work split of the resident kernel: every sample's row groups in runs of gpw, wps waves per sample.
 struct ResidentSplit {
   int groups, wps, gpw;
@@ -936,47 +986,63 @@ inline ResidentSplit resident_split(int n_rows, int64_t batch, int block_waves) 
   return r;
 }
 
-// Which kernel a launch gets: the split-bf16 one when such a mode is on and a weight-image
-// buffer is there, else the weights-resident one where it applies, else the tiled float32 one.
-inline bool takes_split(const void* wpack) { return mode_pieces(g_matmul_mode) > 0 && wpack != nullptr; }
+// Which kernel a launch gets: a weights-resident one where it applies (float32, or bf16 operands in
+// GUNET_MATMUL_BF16 mode); else, in the bf16 / split-bf16 modes and with a weight-image buffer at
+// hand, the tiled split kernel; else the tiled float32 one.
 inline bool takes_resident(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
-  return !takes_split(wpack) && resident_ok(g, nt, batch);
+  (void)wpack;
+  return resident_ok(g, nt, batch);
 }
+inline bool takes_split(const void* wpack) { return mode_pieces(g_matmul_mode) > 0 && wpack != nullptr; }
 
 // Rows of column-sum partials per sample that a launch writes (from colsum_tile0 on).
 inline int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
   if (g.n_rows == 0) return 0;
-  if (takes_resident(g, nt, batch, wpack))
-    return resident_split(g.n_rows, batch, (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves).wps;
+  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, resident_block_waves(g, nt)).wps;
   return static_cast<int>(ceil_div(g.n_rows, kBM));
 }
 
-template <int NT, int NKT, bool GATHER = false>
+template <int NT, int NKT, bool GATHER, bool BF16>
 int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   static bool raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
-  const size_t lds = resident_lds_bytes(NT, NKT);
+  const size_t lds = resident_lds_bytes(NT, NKT, BF16);
   int dev = 0;
   GUNET_HIP_TRY(hipGetDevice(&dev));
   GUNET_REQUIRE(dev >= 0 && dev < 64, "launch_gemm: device index %d", dev);
   if (!raised[dev]) {
-    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER>),
+    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER, BF16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResMaxLds)));
     raised[dev] = true;
   }
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
   const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kWaves));
-  k_gemm_resident<NT, NKT, GATHER><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw, static_cast<int>(batch));
+  k_gemm_resident<NT, NKT, GATHER, BF16><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw,
+                                                                             static_cast<int>(batch));
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
 int launch_gemm_resident(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
   const int kt = gemm_ktiles(g);
+  if (bf16_mode()) {
+    if (g.gather_table != nullptr)
+      return kt == 8 ? launch_resident_inst<4, 8, true, true>(g, batch, stream)
+                     : launch_resident_inst<4, 12, true, true>(g, batch, stream);
+    if (nt == 4)
+      return kt == 4 ? launch_resident_inst<4, 4, false, true>(g, batch, stream)
+                     : launch_resident_inst<4, 8, false, true>(g, batch, stream);
+    return kt == 4 ? launch_resident_inst<3, 4, false, true>(g, batch, stream)
+                   : launch_resident_inst<3, 8, false, true>(g, batch, stream);
+  }
   if (g.gather_table != nullptr)
-    return nt == 4 ? launch_resident_inst<4, 8, true>(g, batch, stream) : launch_resident_inst<2, 12, true>(g, batch, stream);
-  if (nt == 4) return kt == 4 ? launch_resident_inst<4, 4>(g, batch, stream) : launch_resident_inst<4, 8>(g, batch, stream);
-  return kt == 4 ? launch_resident_inst<3, 4>(g, batch, stream) : launch_resident_inst<3, 8>(g, batch, stream);
+    return nt == 4 ? launch_resident_inst<4, 8, true, false>(g, batch, stream)
+                   : launch_resident_inst<2, 12, true, false>(g, batch, stream);
+  if (nt == 4)
+    return kt == 4 ? launch_resident_inst<4, 4, false, false>(g, batch, stream)
+                   : launch_resident_inst<4, 8, false, false>(g, batch, stream);
+  return kt == 4 ? launch_resident_inst<3, 4, false, false>(g, batch, stream)
+                 : launch_resident_inst<3, 8, false, false>(g, batch, stream);
 }
 
 // wpack: scratch of at least wpack_bytes(gemm_ktiles(g), nt) for the split modes (may be null in
@@ -993,13 +1059,15 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
       return GUNET_ERR_INVALID;
     }
   }
-  const bool split = takes_split(wpack), resident = !split && resident_ok(g, nt, batch);
+  const bool resident = resident_ok(g, nt, batch), split = !resident && takes_split(wpack);
   double flops = 0.0;
   for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
   const int kt_all = gemm_ktiles(g);
   ProfScope prof(split ? kProfGemmSplit
                        : (!resident ? kProfGemmTiled
-                                    : (kt_all == 4 ? kProfGemmRes128 : (kt_all == 8 ? kProfGemmRes256 : kProfGemmRes384))),
+                                    : (bf16_mode() ? kProfGemmResBf16
+                                                   : (kt_all == 4 ? kProfGemmRes128
+                                                                  : (kt_all == 8 ? kProfGemmRes256 : kProfGemmRes384)))),
                  stream, flops);
   if (split) {
     const int pieces = mode_pieces(g_matmul_mode);
@@ -1718,7 +1786,9 @@ GemmArgs columns_block(const GemmArgs& g, int units, int col0, int nt, const flo
 
 // Column tiles per launch: 128 columns, except 64 for the gathering GEMM with three operand
 // segments (its weights fill LDS at that width).
-inline int columns_nt(const GemmArgs& g) { return (g.gather_table != nullptr && gemm_ktiles(g) == 12) ? 2 : 4; }
+inline int columns_nt(const GemmArgs& g) {
+  return (g.gather_table != nullptr && gemm_ktiles(g) == 12 && !bf16_mode()) ? 2 : 4;
+}
 
 // Column-sum partial rows per sample such a GEMM writes (the same for each of its column blocks).
 inline int columns_colsum_rows(const GemmArgs& g, int units, int64_t batch, const void* wpack) {
