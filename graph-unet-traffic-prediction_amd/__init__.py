@@ -15,6 +15,7 @@ from .layers import hybrid_gnn, graph_ops
 from .data import data_utils
 from .models import graph_unet, base_model
 from . import evaluation, submission
+from .capture import CapturedForward
 from .models.graph_unet import GraphUNet
 
 __all__ = ['GunetError', 'LIB_PATH', 'set_matmul_mode', 'get_matmul_mode', 'plan', 'layers', 'hybrid_gnn', 'graph_ops', 'data_utils',

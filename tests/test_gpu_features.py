@@ -399,3 +399,22 @@ def test_gn_layer_fused_aggregation_edge_cases(amd, oracle, resident_kernels):
                             x_skip=xt[:, 128:].contiguous().unsqueeze(0).repeat(3, 1, 1))
     for b in range(3):
         assert torch.equal(bx[b], got_x) and torch.equal(bg['global'][b], got_g['global'][0])
+
+
+def test_captured_forward(amd, oracle):
+    """The forward replayed as one HIP graph gives the eager results bit for bit, for new inputs too."""
+    x, graph, _ = make_case(oracle, 40, 52, 0.45)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _unet(amd, oracle, W)
+    g = graph_to_dev(graph)
+    xt = to_dev(x)
+    eager = model.predict(xt, dict(g)).clone()
+    cap = amd.CapturedForward(model, xt, g)
+    assert torch.equal(cap(xt), eager)
+    x2 = to_dev(np.ascontiguousarray(x[::-1] * np.float32(0.5)))
+    glob2 = g['global'] * 1.5
+    g2 = dict(g)
+    g2['global'] = glob2
+    eager2 = model.predict(x2, g2).clone()
+    assert torch.equal(cap(x2, glob=glob2), eager2)
+    assert torch.equal(cap(xt, glob=g['global']), eager)
