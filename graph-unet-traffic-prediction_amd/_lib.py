@@ -47,6 +47,19 @@ class GnWeightsStruct(C.Structure):
                 ('global_scale_nodes', C.c_float), ('global_scale_edges', C.c_float)]
 
 
+MAX_DEPTH = 8
+
+
+class UNetWeightsStruct(C.Structure):
+    _fields_ = [('depth', C.c_int32), ('c_in', C.c_int32), ('out_units', C.c_int32),
+                ('in_kernel', C.c_void_p), ('in_bias', C.c_void_p),
+                ('out_kernel', C.c_void_p), ('out_bias', C.c_void_p),
+                ('down', GnWeightsStruct * MAX_DEPTH),
+                ('bottleneck', GnWeightsStruct * 2),
+                ('up_sampling', GnWeightsStruct * MAX_DEPTH),
+                ('up_gcn', (GnWeightsStruct * 2) * MAX_DEPTH)]
+
+
 VoidP4 = C.c_void_p * 4
 I64x4 = C.c_int64 * 4
 PROF_CLASSES = 13
@@ -94,6 +107,18 @@ SIGNATURES = {
                                                 C.POINTER(GnWeightsStruct), C.c_int32, C.c_void_p,
                                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    'gunet_plan_create': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(VoidP4), C.POINTER(I64x4), C.c_int32,
+                                    C.POINTER(C.c_void_p), C.c_void_p]),
+    'gunet_plan_destroy': (C.c_int, [C.c_void_p]),
+    'gunet_plan_depth': (C.c_int, [C.c_void_p]),
+    'gunet_plan_level': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QuadGraphStruct), C.POINTER(C.c_void_p)]),
+    'gunet_plan_pooling': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(VoidP4)]),
+    'gunet_plan_upsampling': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QuadGraphStruct),
+                                        C.POINTER(C.c_void_p)]),
+    'gunet_unet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32]),
+    'gunet_unet_forward_f32': (C.c_int, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32, C.c_void_p,
+                                         C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.POINTER(VoidP4), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'gunet_street_encoding_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_void_p, C.c_void_p]),
     'gunet_edge_features_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,

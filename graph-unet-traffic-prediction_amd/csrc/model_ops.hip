@@ -1,0 +1,521 @@
+// Whole-model entry points.
+//   gunet_plan_*            every index structure the U-Net needs for one city graph -- per level the
+//                           quadrant graph with its CSRs and in-edge table, the 2x2 pooling maps
+//                           (layers/hybrid_gnn.py:410-447) and the upsampling graphs (:267-280, :336-357)
+//                           -- built once on the device and owned by an opaque handle;
+//   gunet_unet_forward_f32  models/graph_unet.py:61-84 GraphUNet.call as one asynchronous,
+//                           allocation-free call over caller workspace: the same kernels in the same
+//                           order as the layer-by-layer entry points, so results are bit-identical.
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+struct gunet_plan {
+  struct Level {   // one quadrant graph (a U-Net level, or an upsampling graph)
+    int64_t n_nodes = 0;
+    int64_t* node_loc = nullptr;   // [n_nodes, 2]; null for upsampling graphs
+    int32_t* edge_index[4] = {};
+    int64_t n_edges[4] = {};
+    int32_t* rowptr[4] = {};
+    int32_t* perm[4] = {};
+    int32_t* in_table = nullptr;
+    int32_t max_in_degree = 0;
+    gunet_quadgraph qg = {};
+  };
+  struct Pool {   // level l -> l + 1
+    int32_t* cluster = nullptr;
+    int32_t* cluster_rowptr = nullptr;
+    int32_t* cluster_perm = nullptr;
+    int32_t* dup_map[4] = {};
+    int32_t* dup_rowptr[4] = {};
+    int32_t* dup_perm[4] = {};
+  };
+  int depth = 0;
+  int device = 0;
+  std::vector<Level> levels;   // depth + 1
+  std::vector<Pool> pools;     // depth
+  std::vector<Level> ups;      // depth; ups[l]: level l + 1 -> level l, over n_{l+1} + n_l nodes
+  std::vector<int32_t*> parents;
+  std::vector<char> one_parent_edge;   // ups[l] has exactly one edge per fine node (see build_plan)
+  std::vector<void*> owned;
+
+  ~gunet_plan() {
+    for (void* p : owned) (void)hipFree(p);
+  }
+};
+
+namespace gunet {
+namespace {
+
+template <typename T>
+int plan_alloc(gunet_plan& P, T** out, int64_t count) {
+  void* p = nullptr;
+  const size_t bytes = sizeof(T) * static_cast<size_t>(count > 0 ? count : 1);
+  GUNET_HIP_TRY(hipMalloc(&p, bytes));
+  P.owned.push_back(p);
+  *out = static_cast<T*>(p);
+  return GUNET_OK;
+}
+
+// CSRs and in-edge table of a level whose edge lists are in place.
+int finish_quadgraph(gunet_plan& P, gunet_plan::Level& L, hipStream_t stream) {
+  GUNET_REQUIRE(L.n_nodes < INT32_MAX, "plan: too many nodes");
+  const int32_t n = static_cast<int32_t>(L.n_nodes);
+  L.qg = {};
+  L.qg.n_nodes = n;
+  for (int q = 0; q < 4; ++q) {
+    GUNET_TRY(plan_alloc(P, &L.rowptr[q], static_cast<int64_t>(n) + 1));
+    GUNET_TRY(plan_alloc(P, &L.perm[q], L.n_edges[q]));
+    GUNET_TRY(gunet_csr_build(L.edge_index[q], L.n_edges[q], n, L.rowptr[q], L.perm[q], stream));
+    L.qg.n_edges[q] = static_cast<int32_t>(L.n_edges[q]);
+    L.qg.edge_index[q] = L.edge_index[q];
+    L.qg.rowptr[q] = L.rowptr[q];
+    L.qg.perm[q] = L.perm[q];
+  }
+  if (n > 0) {
+    int32_t* table = nullptr;
+    GUNET_TRY(plan_alloc(P, &table, static_cast<int64_t>(n) * 12));
+    GUNET_TRY(gunet_in_edge_table(&L.qg, table, &L.max_in_degree, stream));
+    if (L.max_in_degree <= 3) {
+      L.in_table = table;
+      L.qg.in_table = table;
+    }
+  }
+  return GUNET_OK;
+}
+
+int build_plan(gunet_plan& P, const int64_t* node_loc, int64_t n_nodes, const int32_t* const edge_index[4],
+               const int64_t n_edges[4], hipStream_t stream) {
+  const int D = P.depth;
+  P.levels.resize(D + 1);
+  P.pools.resize(D);
+  P.ups.resize(D);
+  P.parents.assign(D, nullptr);
+  P.one_parent_edge.assign(D, 1);
+  {  // level 0: the plan keeps its own copy of the caller's index tensors
+    gunet_plan::Level& L = P.levels[0];
+    L.n_nodes = n_nodes;
+    GUNET_TRY(plan_alloc(P, &L.node_loc, 2 * n_nodes));
+    if (n_nodes > 0)
+      GUNET_HIP_TRY(hipMemcpyAsync(L.node_loc, node_loc, sizeof(int64_t) * 2 * n_nodes, hipMemcpyDeviceToDevice, stream));
+    for (int q = 0; q < 4; ++q) {
+      L.n_edges[q] = n_edges[q];
+      GUNET_TRY(plan_alloc(P, &L.edge_index[q], 2 * n_edges[q]));
+      if (n_edges[q] > 0)
+        GUNET_HIP_TRY(hipMemcpyAsync(L.edge_index[q], edge_index[q], sizeof(int32_t) * 2 * n_edges[q],
+                                     hipMemcpyDeviceToDevice, stream));
+    }
+    GUNET_TRY(finish_quadgraph(P, L, stream));
+  }
+  for (int l = 0; l < D; ++l) {   // graph_pooling_2x2, index part (hybrid_gnn.py:415-434, 391-408)
+    const gunet_plan::Level& F = P.levels[l];
+    gunet_plan::Level& C = P.levels[l + 1];
+    gunet_plan::Pool& pool = P.pools[l];
+    const int64_t n = F.n_nodes;
+    GUNET_TRY(plan_alloc(P, &pool.cluster, n));
+    GUNET_TRY(plan_alloc(P, &C.node_loc, 2 * n));
+    int64_t n_pooled = 0;
+    GUNET_TRY(gunet_cluster_ids(F.node_loc, n, pool.cluster, C.node_loc, &n_pooled, stream));
+    C.n_nodes = n_pooled;
+    GUNET_TRY(plan_alloc(P, &pool.cluster_rowptr, n_pooled + 1));
+    GUNET_TRY(plan_alloc(P, &pool.cluster_perm, n));
+    GUNET_TRY(gunet_csr_from_keys(pool.cluster, n, static_cast<int32_t>(n_pooled), pool.cluster_rowptr,
+                                  pool.cluster_perm, stream));
+    for (int q = 0; q < 4; ++q) {
+      const int64_t ne = F.n_edges[q];
+      GUNET_TRY(plan_alloc(P, &C.edge_index[q], 2 * ne));
+      GUNET_TRY(plan_alloc(P, &pool.dup_map[q], ne));
+      int64_t n_new = 0;
+      if (ne > 0)
+        GUNET_TRY(gunet_pool_edges(F.edge_index[q], ne, pool.cluster, n > 0 ? n : 1, C.edge_index[q], pool.dup_map[q],
+                                   &n_new, stream));
+      C.n_edges[q] = n_new;
+      GUNET_TRY(plan_alloc(P, &pool.dup_rowptr[q], n_new + 1));
+      GUNET_TRY(plan_alloc(P, &pool.dup_perm[q], ne));
+      GUNET_TRY(gunet_csr_from_keys(pool.dup_map[q], ne, static_cast<int32_t>(n_new), pool.dup_rowptr[q],
+                                    pool.dup_perm[q], stream));
+    }
+    GUNET_TRY(finish_quadgraph(P, C, stream));
+  }
+  for (int l = 0; l < D; ++l) {   // GraphUpsampling2x2 'graph', index part (hybrid_gnn.py:270-280, 336-357)
+    const gunet_plan::Level& F = P.levels[l];
+    const gunet_plan::Level& C = P.levels[l + 1];
+    gunet_plan::Level& U = P.ups[l];
+    U.n_nodes = C.n_nodes + F.n_nodes;
+    GUNET_TRY(plan_alloc(P, &P.parents[l], F.n_nodes));
+    int32_t* lists[4];
+    for (int q = 0; q < 4; ++q) {
+      GUNET_TRY(plan_alloc(P, &U.edge_index[q], 2 * F.n_nodes));
+      lists[q] = U.edge_index[q];
+    }
+    int64_t counts[4] = {};
+    GUNET_TRY(gunet_upsample_edges(C.node_loc, C.n_nodes, F.node_loc, F.n_nodes, P.parents[l], lists, counts, stream));
+    int64_t total = 0;
+    for (int q = 0; q < 4; ++q) {
+      U.n_edges[q] = counts[q];
+      total += counts[q];
+    }
+    // The reference's cell id (row // 2) * (max_row + 1) + col // 2 (hybrid_gnn.py:417-423) is not
+    // unique when the graph is more than twice as wide as it is high; merged cells then leave fine
+    // nodes that sit in none of the four places around their parent's position and get no edge
+    // (:353-357).  Such a level takes the reference's literal route in the forward: the GN layer on
+    // [x ; zeros].
+    P.one_parent_edge[l] = total == F.n_nodes;
+    GUNET_TRY(finish_quadgraph(P, U, stream));
+  }
+  GUNET_HIP_TRY(hipStreamSynchronize(stream));
+  return GUNET_OK;
+}
+
+// out[b] = [a[b] | c[b]]
+__global__ void k_concat_rows(const float* __restrict__ a, int wa, const float* __restrict__ c, int wc,
+                              float* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < wa + wc; i += blockDim.x)
+    out[static_cast<int64_t>(b) * (wa + wc) + i] = i < wa ? a[static_cast<int64_t>(b) * wa + i]
+                                                         : c[static_cast<int64_t>(b) * wc + (i - wa)];
+}
+
+// dst[b, 0..row_floats) = src[b, 0..row_floats) for rows that are src_stride / dst_stride floats apart
+__global__ void k_copy_rows(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst,
+                            int64_t dst_stride, int64_t row_floats) {
+  const int64_t b = blockIdx.y;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < row_floats;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    dst[b * dst_stride + i] = src[b * src_stride + i];
+}
+
+int copy_rows(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t row_floats, int64_t batch,
+              hipStream_t stream) {
+  if (row_floats == 0 || batch == 0) return GUNET_OK;
+  const int64_t blocks = ceil_div(row_floats, 256);
+  dim3 grid(static_cast<unsigned>(blocks < 4096 ? blocks : 4096), static_cast<unsigned>(batch));
+  k_copy_rows<<<grid, 256, 0, stream>>>(src, src_stride, dst, dst_stride, row_floats);
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+inline int global_out_width(const gunet_gn_weights& w) {
+  return w.globt_w != nullptr ? w.units : w.g + w.units + w.units / 4;
+}
+
+// Bump allocation over the caller's workspace (base == nullptr: size query).
+struct Carver {
+  char* base;
+  size_t off = 0;
+  float* take(int64_t floats) {
+    off = (off + 255) & ~static_cast<size_t>(255);
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += sizeof(float) * static_cast<size_t>(floats > 0 ? floats : 0);
+    return p;
+  }
+};
+
+struct EdgeSet {
+  float* q[4];
+};
+
+struct ModelBuffers {
+  float* skip_x[GUNET_MAX_DEPTH + 1];
+  EdgeSet skip_e[GUNET_MAX_DEPTH + 1];   // [0] unused: the caller's tensors
+  float* skip_g[GUNET_MAX_DEPTH + 1];    // [0] unused
+  float* tmp_x[2];
+  EdgeSet tmp_e[2];
+  float* up_in;    // [x ; zeros] and the full output of an upsampling layer on the literal route
+  float* up_out;
+  float* globals;        // one [B, max_g] slot per layer
+  int64_t global_slot;   // floats per slot
+  void* layer_ws;
+  size_t layer_ws_bytes;
+  size_t bytes;
+};
+
+// Checks that the weights chain (every layer's c_in, f_e, g follows from the one before, as
+// models/graph_unet.py:61-84 wires them) and lays the intermediates out.
+int carve_model(const char* who, const gunet_plan* P, const gunet_unet_weights* w, int64_t batch, void* workspace,
+                ModelBuffers* mb, int* final_width) {
+  const int D = P->depth;
+  GUNET_REQUIRE(w->depth == D, "%s: weights of depth %d for a plan of depth %d", who, w->depth, D);
+  GUNET_REQUIRE(D >= 1, "%s: depth %d (at least one down/up block is needed)", who, D);
+  GUNET_REQUIRE(w->c_in > 0 && w->out_units > 0 && w->in_kernel && w->out_kernel, "%s: null or empty dense layer", who);
+  int wx[GUNET_MAX_DEPTH + 1], we[GUNET_MAX_DEPTH + 1], wg[GUNET_MAX_DEPTH + 1];
+  int max_units = 0, max_g = 0;
+  size_t layer_ws = 0;
+  auto check = [&](const char* name, int idx, const gunet_gn_weights& g, int c_in, int f_e, int gw,
+                   const gunet_quadgraph& graph) -> int {
+    GUNET_REQUIRE(g.units == 128 || g.units == 256, "%s: %s[%d] is %d wide (128 and 256 are implemented)", who, name,
+                  idx, g.units);
+    GUNET_REQUIRE(g.c_in == c_in && g.f_e == f_e && g.g == gw,
+                  "%s: %s[%d] has c_in, f_e, g = %d, %d, %d; the layers before it give %d, %d, %d", who, name, idx,
+                  g.c_in, g.f_e, g.g, c_in, f_e, gw);
+    max_units = g.units > max_units ? g.units : max_units;
+    const int go = global_out_width(g);
+    max_g = go > max_g ? go : max_g;
+    max_g = gw > max_g ? gw : max_g;
+    const size_t b = gunet_gn_layer_workspace_bytes(&graph, static_cast<int32_t>(batch), g.units);
+    layer_ws = b > layer_ws ? b : layer_ws;
+    return GUNET_OK;
+  };
+  wx[0] = w->down[0].c_in;
+  we[0] = w->down[0].f_e;
+  wg[0] = w->down[0].g;
+  GUNET_REQUIRE(wx[0] > 0 && wx[0] % 32 == 0, "%s: in_layer width %d", who, wx[0]);
+  for (int l = 0; l < D; ++l) {
+    GUNET_TRY(check("down", l, w->down[l], wx[l], we[l], wg[l], P->levels[l].qg));
+    wx[l + 1] = w->down[l].units;
+    we[l + 1] = w->down[l].units / 4;
+    wg[l + 1] = global_out_width(w->down[l]);
+  }
+  int c = wx[D], fe = we[D], g = wg[D];
+  for (int i = 0; i < 2; ++i) {
+    GUNET_TRY(check("bottleneck", i, w->bottleneck[i], c, fe, g, P->levels[D].qg));
+    c = w->bottleneck[i].units;
+    fe = c / 4;
+    g = global_out_width(w->bottleneck[i]);
+  }
+  for (int i = 0; i < D; ++i) {
+    const int l = D - 1 - i;
+    GUNET_TRY(check("up_sampling", i, w->up_sampling[i], c, 2, g + wg[l], P->ups[l].qg));
+    c = w->up_sampling[i].units;
+    g = global_out_width(w->up_sampling[i]);
+    GUNET_TRY(check("up_gcn0", i, w->up_gcn[i][0], c + wx[l], we[l], g, P->levels[l].qg));
+    c = w->up_gcn[i][0].units;
+    fe = c / 4;
+    g = global_out_width(w->up_gcn[i][0]);
+    GUNET_TRY(check("up_gcn1", i, w->up_gcn[i][1], c, fe, g, P->levels[l].qg));
+    c = w->up_gcn[i][1].units;
+    fe = c / 4;
+    g = global_out_width(w->up_gcn[i][1]);
+  }
+  *final_width = c;
+
+  Carver cv{static_cast<char*>(workspace)};
+  int64_t max_rows = 0, max_edges[4] = {};
+  for (int l = 0; l <= D; ++l) {
+    const gunet_plan::Level& L = P->levels[l];
+    max_rows = L.n_nodes > max_rows ? L.n_nodes : max_rows;
+    mb->skip_x[l] = cv.take(batch * L.n_nodes * wx[l]);
+    mb->skip_g[l] = l > 0 ? cv.take(batch * wg[l]) : nullptr;
+    for (int q = 0; q < 4; ++q) {
+      max_edges[q] = L.n_edges[q] > max_edges[q] ? L.n_edges[q] : max_edges[q];
+      mb->skip_e[l].q[q] = l > 0 ? cv.take(batch * L.n_edges[q] * we[l]) : nullptr;
+    }
+  }
+  int64_t literal_rows = 0;   // upsampling levels without the one-edge-per-fine-node structure
+  for (int l = 0; l < D; ++l) {
+    if (P->one_parent_edge[l]) continue;
+    const gunet_plan::Level& U = P->ups[l];
+    literal_rows = U.n_nodes > literal_rows ? U.n_nodes : literal_rows;
+    for (int q = 0; q < 4; ++q) max_edges[q] = U.n_edges[q] > max_edges[q] ? U.n_edges[q] : max_edges[q];
+  }
+  mb->up_in = cv.take(batch * literal_rows * max_units);
+  mb->up_out = cv.take(batch * literal_rows * max_units);
+  for (int i = 0; i < 2; ++i) {
+    mb->tmp_x[i] = cv.take(batch * max_rows * max_units);
+    for (int q = 0; q < 4; ++q) mb->tmp_e[i].q[q] = cv.take(batch * max_edges[q] * (max_units / 4));
+  }
+  mb->global_slot = (batch * max_g + 63) / 64 * 64;
+  mb->globals = cv.take(mb->global_slot * (2 + 4 * D));
+  const size_t dense_ws = gunet_dense_workspace_bytes(w->c_in, wx[0]);
+  const size_t dense_ws2 = gunet_dense_workspace_bytes(c, w->out_units);
+  layer_ws = dense_ws > layer_ws ? dense_ws : layer_ws;
+  layer_ws = dense_ws2 > layer_ws ? dense_ws2 : layer_ws;
+  mb->layer_ws = cv.take(static_cast<int64_t>((layer_ws + 3) / 4));
+  mb->layer_ws_bytes = layer_ws;
+  mb->bytes = cv.off + 256;
+  return GUNET_OK;
+}
+
+}  // namespace
+}  // namespace gunet
+
+using namespace gunet;
+
+extern "C" {
+
+int gunet_plan_create(const int64_t* node_loc, int64_t n_nodes, const int32_t* const edge_index[4],
+                      const int64_t n_edges[4], int32_t depth, gunet_plan** plan_out, gunet_stream_t stream) {
+  GUNET_REQUIRE(plan_out != nullptr, "plan_create: plan_out is null");
+  *plan_out = nullptr;
+  GUNET_REQUIRE(depth >= 0 && depth <= GUNET_MAX_DEPTH, "plan_create: depth %d outside 0..%d", depth, GUNET_MAX_DEPTH);
+  GUNET_REQUIRE(n_nodes >= 0 && n_nodes < INT32_MAX && edge_index && n_edges, "plan_create: bad arguments");
+  GUNET_REQUIRE(n_nodes == 0 || node_loc, "plan_create: node_loc is null");
+  for (int q = 0; q < 4; ++q)
+    GUNET_REQUIRE(n_edges[q] >= 0 && n_edges[q] < INT32_MAX && (n_edges[q] == 0 || edge_index[q]),
+                  "plan_create: bad edge list %d", q);
+  gunet_plan* P = new (std::nothrow) gunet_plan;
+  GUNET_REQUIRE(P != nullptr, "plan_create: out of host memory");
+  P->depth = depth;
+  int rc = hipGetDevice(&P->device) == hipSuccess ? GUNET_OK : GUNET_ERR_HIP;
+  if (rc != GUNET_OK) set_error("plan_create: hipGetDevice failed");
+  if (rc == GUNET_OK) rc = build_plan(*P, node_loc, n_nodes, edge_index, n_edges, as_stream(stream));
+  if (rc != GUNET_OK) {
+    delete P;
+    return rc;
+  }
+  *plan_out = P;
+  return GUNET_OK;
+}
+
+int gunet_plan_destroy(gunet_plan* plan) {
+  delete plan;
+  return GUNET_OK;
+}
+
+int gunet_plan_depth(const gunet_plan* plan) { return plan ? plan->depth : GUNET_ERR_INVALID; }
+
+int gunet_plan_level(const gunet_plan* plan, int32_t level, gunet_quadgraph* graph_out, const int64_t** node_loc_out) {
+  GUNET_REQUIRE(plan != nullptr, "plan_level: null plan");
+  GUNET_REQUIRE(level >= 0 && level <= plan->depth, "plan_level: level %d outside 0..%d", level, plan->depth);
+  if (graph_out) *graph_out = plan->levels[level].qg;
+  if (node_loc_out) *node_loc_out = plan->levels[level].node_loc;
+  return GUNET_OK;
+}
+
+int gunet_plan_pooling(const gunet_plan* plan, int32_t level, const int32_t** cluster_out,
+                       const int32_t* dup_map_out[4]) {
+  GUNET_REQUIRE(plan != nullptr, "plan_pooling: null plan");
+  GUNET_REQUIRE(level >= 0 && level < plan->depth, "plan_pooling: level %d outside 0..%d", level, plan->depth - 1);
+  if (cluster_out) *cluster_out = plan->pools[level].cluster;
+  if (dup_map_out)
+    for (int q = 0; q < 4; ++q) dup_map_out[q] = plan->pools[level].dup_map[q];
+  return GUNET_OK;
+}
+
+int gunet_plan_upsampling(const gunet_plan* plan, int32_t level, gunet_quadgraph* graph_out,
+                          const int32_t** parent_out) {
+  GUNET_REQUIRE(plan != nullptr, "plan_upsampling: null plan");
+  GUNET_REQUIRE(level >= 0 && level < plan->depth, "plan_upsampling: level %d outside 0..%d", level, plan->depth - 1);
+  if (graph_out) *graph_out = plan->ups[level].qg;
+  if (parent_out) *parent_out = plan->parents[level];
+  return GUNET_OK;
+}
+
+size_t gunet_unet_workspace_bytes(const gunet_plan* plan, const gunet_unet_weights* weights, int32_t batch) {
+  if (plan == nullptr || weights == nullptr || batch <= 0) return 0;
+  ModelBuffers mb;
+  int final_width = 0;
+  if (carve_model("unet_workspace_bytes", plan, weights, batch, nullptr, &mb, &final_width) != GUNET_OK) return 0;
+  return mb.bytes;
+}
+
+int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
+                           const float* const edges[4], const float* global_in, int32_t activation,
+                           int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
+                           void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
+  hipStream_t stream = as_stream(stream_);
+  GUNET_REQUIRE(P && w, "unet_forward: null plan or weights");
+  GUNET_REQUIRE(batch > 0, "unet_forward: batch %d", batch);
+  GUNET_REQUIRE(x && edges && global_in && out, "unet_forward: null tensor");
+  GUNET_REQUIRE(workspace != nullptr && reinterpret_cast<uintptr_t>(workspace) % 256 == 0,
+                "unet_forward: the workspace must be 256-byte aligned");
+  int dev = 0;
+  GUNET_HIP_TRY(hipGetDevice(&dev));
+  GUNET_REQUIRE(dev == P->device, "unet_forward: the plan lives on device %d, the current device is %d", P->device, dev);
+  ModelBuffers mb;
+  int final_width = 0;
+  GUNET_TRY(carve_model("unet_forward", P, w, batch, workspace, &mb, &final_width));
+  if (workspace_bytes < mb.bytes) {
+    set_error("unet_forward: workspace of %zu bytes, %zu needed", workspace_bytes, mb.bytes);
+    return GUNET_ERR_WORKSPACE;
+  }
+  const int D = P->depth;
+  const int64_t B = batch;
+  int slot = 0;
+  auto next_global = [&]() { return mb.globals + mb.global_slot * slot++; };
+
+  // in_layer (graph_unet.py:37, :66): Dense with bias, no activation
+  GUNET_TRY(gunet_dense_forward_f32(x, B * P->levels[0].n_nodes, w->c_in, w->in_kernel, w->in_bias, w->down[0].c_in,
+                                    GUNET_ACT_LINEAR, mb.skip_x[0], mb.layer_ws, mb.layer_ws_bytes, stream));
+
+  // down path (:67-71): GN layer, then 2x2 pooling; what enters each block stays for the way up
+  const float* cur_g = global_in;
+  for (int l = 0; l < D; ++l) {
+    const gunet_plan::Level& L = P->levels[l];
+    const gunet_plan::Level& C = P->levels[l + 1];
+    const gunet_plan::Pool& pool = P->pools[l];
+    const gunet_gn_weights& gw = w->down[l];
+    const float* const* e_in = l == 0 ? edges : mb.skip_e[l].q;
+    GUNET_TRY(gunet_gn_layer_forward_f32(&L.qg, &gw, batch, mb.skip_x[l], nullptr, 0, e_in, cur_g, activation,
+                                         mb.tmp_x[0], mb.tmp_e[0].q, mb.skip_g[l + 1], mb.layer_ws, mb.layer_ws_bytes,
+                                         stream));
+    cur_g = mb.skip_g[l + 1];
+    GUNET_TRY(gunet_segment_max_f32(mb.tmp_x[0], L.n_nodes, gw.units, pool.cluster_rowptr, pool.cluster_perm,
+                                    C.n_nodes, batch, mb.skip_x[l + 1], stream));
+    for (int q = 0; q < 4; ++q)
+      GUNET_TRY(gunet_segment_max_f32(mb.tmp_e[0].q[q], L.n_edges[q], gw.units / 4, pool.dup_rowptr[q], pool.dup_perm[q],
+                                      C.n_edges[q], batch, mb.skip_e[l + 1].q[q], stream));
+  }
+
+  // bottleneck (:73-74)
+  const float* cur_x = mb.skip_x[D];
+  const float* const* cur_e = mb.skip_e[D].q;
+  int side = 0;   // tmp buffer the next layer writes
+  for (int i = 0; i < 2; ++i) {
+    float* g_out = next_global();
+    GUNET_TRY(gunet_gn_layer_forward_f32(&P->levels[D].qg, &w->bottleneck[i], batch, cur_x, nullptr, 0, cur_e, cur_g,
+                                         activation, mb.tmp_x[side], mb.tmp_e[side].q, g_out, mb.layer_ws,
+                                         mb.layer_ws_bytes, stream));
+    cur_x = mb.tmp_x[side];
+    cur_e = mb.tmp_e[side].q;
+    cur_g = g_out;
+    side ^= 1;
+  }
+
+  // up path (:76-80): graph upsampling, skip concatenation, two GN layers
+  for (int i = 0; i < D; ++i) {
+    const int l = D - 1 - i;
+    const gunet_plan::Level& L = P->levels[l];
+    const gunet_plan::Level& C = P->levels[l + 1];
+    const gunet_gn_weights& up = w->up_sampling[i];
+    const float* target_g = l == 0 ? global_in : mb.skip_g[l];
+    const int wa = up.g - (l == 0 ? w->down[0].g : global_out_width(w->down[l - 1]));
+    float* g_cat = next_global();
+    k_concat_rows<<<batch, 256, 0, stream>>>(cur_g, wa, target_g, up.g - wa, g_cat);   // hybrid_gnn.py:375
+    GUNET_LAUNCH_CHECK();
+    float* g_up = next_global();
+    if (P->one_parent_edge[l]) {
+      GUNET_TRY(gunet_gn_upsample_forward_f32(&P->ups[l].qg, static_cast<int32_t>(C.n_nodes), &up, batch, cur_x, g_cat,
+                                              activation, mb.tmp_x[side], g_up, mb.layer_ws, mb.layer_ws_bytes,
+                                              stream));
+    } else {   // hybrid_gnn.py:342-344, 373-377 as written: the layer on [x ; zeros] with zero edge features
+      const int64_t n_all = C.n_nodes + L.n_nodes;
+      GUNET_HIP_TRY(hipMemsetAsync(mb.up_in, 0, sizeof(float) * B * n_all * up.c_in, stream));
+      GUNET_TRY(copy_rows(cur_x, C.n_nodes * up.c_in, mb.up_in, n_all * up.c_in, C.n_nodes * up.c_in, B, stream));
+      const float* no_edges[4] = {};
+      GUNET_TRY(gunet_gn_layer_forward_f32(&P->ups[l].qg, &up, batch, mb.up_in, nullptr, 0, no_edges, g_cat, activation,
+                                           mb.up_out, mb.tmp_e[side].q, g_up, mb.layer_ws, mb.layer_ws_bytes, stream));
+      GUNET_TRY(copy_rows(mb.up_out + C.n_nodes * up.units, n_all * up.units, mb.tmp_x[side], L.n_nodes * up.units,
+                          L.n_nodes * up.units, B, stream));
+    }
+    cur_x = mb.tmp_x[side];
+    cur_g = g_up;
+    side ^= 1;
+    const float* const* e_in = l == 0 ? edges : mb.skip_e[l].q;
+    for (int j = 0; j < 2; ++j) {
+      const gunet_gn_weights& gw = w->up_gcn[i][j];
+      const bool last = i == D - 1 && j == 1;
+      float* g_out = last && global_out ? global_out : next_global();
+      float* const* e_out = mb.tmp_e[side].q;
+      float* last_e[4];
+      if (last && edges_out) {
+        for (int q = 0; q < 4; ++q) last_e[q] = edges_out[q] ? edges_out[q] : mb.tmp_e[side].q[q];
+        e_out = last_e;
+      }
+      const int c_skip = j == 0 ? gw.c_in - up.units : 0;   // concat(x, x_skip), hybrid_gnn.py:235
+      GUNET_TRY(gunet_gn_layer_forward_f32(&L.qg, &gw, batch, cur_x, j == 0 ? mb.skip_x[l] : nullptr, c_skip, e_in,
+                                           cur_g, activation, mb.tmp_x[side], e_out, g_out, mb.layer_ws,
+                                           mb.layer_ws_bytes, stream));
+      cur_x = mb.tmp_x[side];
+      e_in = e_out == last_e ? nullptr : mb.tmp_e[side].q;
+      cur_g = g_out;
+      side ^= 1;
+    }
+  }
+  // out_model (:82): Dense without bias
+  return gunet_dense_forward_f32(cur_x, B * P->levels[0].n_nodes, final_width, w->out_kernel, w->out_bias, w->out_units,
+                                 out_activation, out, mb.layer_ws, mb.layer_ws_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,8 +1,12 @@
 """Graph U-Net model (reference models/graph_unet.py:9-84) on libgunet_hip.so."""
+import ctypes as C
+
 import torch
 
-from .. import layers as L
-from ..layers.hybrid_gnn import Dense, GraphDownsamplingBlock, GraphUpsamplingBlock
+from .. import _lib, layers as L, plan as _plan
+from .._lib import UNetWeightsStruct, call, current_stream, ptr, ptr4
+from ..layers.hybrid_gnn import (Dense, GeoQuadrantGCN, GraphDownsamplingBlock, GraphUpsamplingBlock,
+                                 _activation_code, _as_f32)
 from .base_model import GraphBaseModel
 
 
@@ -47,6 +51,12 @@ class GraphUNet(GraphBaseModel):
                                       last_block=i == (self.depth - 1))
             self.upsampling_layers.append(us)
         self.out_model = Dense(out_units, use_bias=False, activation=output_activation)
+        # call() runs the whole forward through one library call (gunet_unet_forward_f32) when the
+        # model is the plain stack of GeoQuadrantGCN layers; False walks the layer objects instead
+        # (same kernels in the same order, identical results).
+        self.native_forward = True
+        self._native_struct = None
+        self._native_key = None
 
     def _gn_layers(self):
         """(checkpoint prefix, layer) for every GeoQuadrantGCN, in the checkpoint's naming."""
@@ -86,7 +96,115 @@ class GraphUNet(GraphBaseModel):
             raise NotImplementedError('predict() needs a linear or relu output activation')
         return self.call(x, graph, training=training, _out_activation='relu')[0]
 
+    # -- whole forward as one library call ---------------------------------------
+    def _native_ok(self):
+        gcns = [g for _, g in self._gn_layers()]
+        blocks = self.downsampling_layers + self.upsampling_layers
+        return (self.native_forward and 1 <= self.depth <= _lib.MAX_DEPTH
+                and all(type(g) is GeoQuadrantGCN and g.use_global for g in gcns)
+                and all(not b.residual for b in blocks)
+                and all(b.n_layers == 1 for b in self.downsampling_layers)
+                and all(b.n_layers == 2 and b.upsampling.method == 'graph' and b.upsampling.col_idx == 0
+                        for b in self.upsampling_layers))
+
+    def _native_weights(self, c_in, f_e, g, device):
+        """The library's weight table for inputs of these widths; layers without loaded weights are
+        initialised on the way (Keras defaults), each with the widths the layers before it give."""
+        key = (c_in, f_e, g, str(device))
+        if self._native_struct is not None and self._native_key == key:
+            return self._native_struct
+        s = UNetWeightsStruct()
+        keep = []
+
+        def put(dst, layer, c, fe, gw):
+            layer.build(c, fe, gw, device)
+            ws = layer._weights_struct(c, fe, gw)
+            keep.append(ws)
+            C.memmove(C.addressof(dst), C.addressof(ws), C.sizeof(ws))
+            gout = layer.units if layer.has_glob_transform else gw + layer.units + layer.units // 4
+            return layer.units, layer.units // 4, gout
+
+        self.in_layer.build(c_in, device)
+        if tuple(self.in_layer.kernel.shape) != (c_in, self.in_layer.units):
+            raise ValueError(f'in_layer/kernel has shape {tuple(self.in_layer.kernel.shape)}, '
+                             f'the inputs need {(c_in, self.in_layer.units)}')
+        s.depth, s.c_in, s.out_units = self.depth, c_in, self.out_model.units
+        s.in_kernel = self.in_layer.kernel.data_ptr()
+        s.in_bias = self.in_layer.bias.data_ptr() if self.in_layer.bias is not None else None
+        wx, we, wg = [self.in_layer.units], [f_e], [g]
+        for l, blk in enumerate(self.downsampling_layers):
+            c, fe, gw = put(s.down[l], blk.gcns[0], wx[l], we[l], wg[l])
+            wx.append(c); we.append(fe); wg.append(gw)
+        c, fe, gw = wx[-1], we[-1], wg[-1]
+        for i, layer in enumerate((self.bottleneck_gcn_1, self.bottleneck_gcn_2)):
+            c, fe, gw = put(s.bottleneck[i], layer, c, fe, gw)
+        for i, blk in enumerate(self.upsampling_layers):
+            l = self.depth - 1 - i
+            c, _, gw = put(s.up_sampling[i], blk.upsampling.gcn, c, 2, gw + wg[l])
+            c, fe, gw = put(s.up_gcn[i][0], blk.gcns[0], c + wx[l], we[l], gw)
+            c, fe, gw = put(s.up_gcn[i][1], blk.gcns[1], c, fe, gw)
+        self.out_model.build(c, device)
+        if tuple(self.out_model.kernel.shape) != (c, self.out_model.units):
+            raise ValueError(f'out_model/kernel has shape {tuple(self.out_model.kernel.shape)}, '
+                             f'the last layer gives {(c, self.out_model.units)}')
+        s.out_kernel = self.out_model.kernel.data_ptr()
+        s.out_bias = self.out_model.bias.data_ptr() if self.out_model.bias is not None else None
+        s._keep = keep
+        self._native_struct, self._native_key = s, key
+        self._native_widths = (fe, gw)
+        return s
+
+    def _call_native(self, x, graph, out_activation):
+        x = _as_f32(x, 'x')
+        single = x.dim() == 2
+        xb = x.unsqueeze(0) if single else x
+        if xb.dim() != 3:
+            raise ValueError(f'x must be [N, C] or [B, N, C], got {tuple(x.shape)}')
+        batch, n, c_in = xb.shape
+        dev = x.device
+        glob = _as_f32(graph['global'], "graph['global']")
+        glob = glob.reshape(-1, glob.shape[-1])
+        if glob.shape[0] != batch:
+            raise ValueError(f"graph['global'] has {glob.shape[0]} rows for a batch of {batch}")
+        edge_index, edges = graph['edge_index'], graph['edges']
+        if len(edge_index) != 4 or len(edges) != 4:
+            raise ValueError('GraphUNet needs 4 edge lists and 4 edge-feature tensors')
+        up = _plan.get_unet_plan(graph['node_loc'], edge_index, self.depth)
+        if up.n_nodes[0] != n:
+            raise ValueError(f"x has {n} rows but graph['node_loc'] has {up.n_nodes[0]}")
+        feats = []
+        for q in range(4):
+            e = _as_f32(edges[q], f"graph['edges'][{q}]")
+            eb = e.unsqueeze(0) if e.dim() == 2 else e
+            if eb.shape[0] != batch or eb.shape[1] != up.n_edges[0][q] or eb.shape[2] != edges[0].shape[-1]:
+                raise ValueError(f"graph['edges'][{q}] has shape {tuple(e.shape)}, expected "
+                                 f'[{batch}, {up.n_edges[0][q]}, {edges[0].shape[-1]}]')
+            feats.append(eb)
+        ws = self._native_weights(c_in, feats[0].shape[2], glob.shape[1], dev)
+        u_last, g_last = self._native_widths
+        out = torch.empty((batch, n, self.out_model.units), dtype=torch.float32, device=dev)
+        edges_out = [torch.empty((batch, up.n_edges[0][q], u_last), dtype=torch.float32, device=dev) for q in range(4)]
+        global_out = torch.empty((batch, g_last), dtype=torch.float32, device=dev)
+        nbytes = int(_lib.lib.gunet_unet_workspace_bytes(up.handle, C.byref(ws), batch))
+        if nbytes == 0:
+            raise NotImplementedError(f'GraphUNet: {_lib.last_error()}')
+        scratch = _plan.model_workspace(nbytes, dev)
+        base = (scratch.data_ptr() + 255) // 256 * 256
+        in_ptrs, out_ptrs = ptr4(feats), ptr4(edges_out)
+        call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
+             _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs), ptr(global_out),
+             C.c_void_p(base), scratch.numel() - (base - scratch.data_ptr()), current_stream(dev))
+        if single:
+            out = out[0]
+            edges_out = [e[0] for e in edges_out]
+        graph['edges'] = edges_out
+        graph['global'] = global_out
+        return out, graph
+
     def call(self, x, graph, training=False, _out_activation=Ellipsis):
+        if self._native_ok():
+            act = self.out_model._act if _out_activation is Ellipsis else _activation_code(_out_activation)
+            return self._call_native(x, graph, act)
         skip_graphs = []
         skips = []
         x = self.in_layer(x)

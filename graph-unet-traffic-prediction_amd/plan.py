@@ -9,6 +9,8 @@ was built from.  The reference recomputes all of it inside every forward
   PoolPlan      2x2 cluster ids, pooled node positions, pooled edge lists and
                 the member lists used by the segment-max kernels
   UpsamplePlan  parent ids and the QuadGraph of the 'graph' upsampling method
+  UNetPlan      all of the above for every level of a U-Net, owned by the library
+                (gunet_plan_create) and consumed by the whole-model entry point
 """
 import ctypes as C
 from collections import OrderedDict
@@ -35,6 +37,7 @@ def clear_caches():
     _quad_cache.clear()
     _pool_cache.clear()
     _up_cache.clear()
+    _unet_cache.clear()
 
 
 def _check_edge_list(e):
@@ -208,6 +211,99 @@ def get_upsample_plan(coarse_loc, fine_loc):
     return _remember(_up_cache, key, plan)
 
 
+class _DeviceView:
+    """A typed window on device memory the library owns, importable with torch.as_tensor."""
+
+    def __init__(self, address, shape, typestr, owner):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(address), False),
+                                         'version': 2}
+        self._owner = owner
+
+
+_TYPESTR = {torch.int32: '<i4', torch.int64: '<i8'}
+
+
+class UNetPlan:
+    """Handle of a library-owned plan: quadrant graphs, pooling maps and upsampling graphs of all
+    depth + 1 levels of one city graph (what QuadGraph / PoolPlan / UpsamplePlan hold level by
+    level), built by one call and passed to gunet_unet_forward_f32."""
+
+    def __init__(self, node_loc, edge_index, depth):
+        node_loc = _check_node_loc(node_loc)
+        edge_index = [_check_edge_list(e) for e in edge_index]
+        if len(edge_index) != 4:
+            raise ValueError('a quadrant graph needs exactly 4 edge lists')
+        self.device = node_loc.device
+        self.depth = int(depth)
+        self.handle = C.c_void_p()
+        lists = ptr4(edge_index)
+        counts = _lib.I64x4(*[int(e.shape[0]) for e in edge_index])
+        with torch.cuda.device(self.device):
+            call('gunet_plan_create', ptr(node_loc), int(node_loc.shape[0]), C.byref(lists), C.byref(counts),
+                 self.depth, C.byref(self.handle), current_stream(self.device))
+        self.n_nodes, self.n_edges = [], []
+        for level in range(self.depth + 1):
+            s = self._level_struct(level)[0]
+            self.n_nodes.append(int(s.n_nodes))
+            self.n_edges.append([int(s.n_edges[q]) for q in range(4)])
+
+    def __del__(self):
+        handle, self.handle = getattr(self, 'handle', None), None
+        if handle and _lib is not None and getattr(_lib, 'lib', None) is not None:
+            _lib.lib.gunet_plan_destroy(handle)
+
+    def _view(self, address, shape, dtype):
+        if any(d == 0 for d in shape):
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        return torch.as_tensor(_DeviceView(address, shape, _TYPESTR[dtype], self), device=self.device)
+
+    def _level_struct(self, level):
+        s, loc = QuadGraphStruct(), C.c_void_p()
+        call('gunet_plan_level', self.handle, level, C.byref(s), C.byref(loc))
+        return s, loc
+
+    def _graph_views(self, s):
+        n = int(s.n_nodes)
+        return {'n_nodes': n,
+                'edge_index': [self._view(s.edge_index[q], (int(s.n_edges[q]), 2), torch.int32) for q in range(4)],
+                'rowptr': [self._view(s.rowptr[q], (n + 1,), torch.int32) for q in range(4)],
+                'perm': [self._view(s.perm[q], (int(s.n_edges[q]),), torch.int32) for q in range(4)],
+                'in_table': self._view(s.in_table, (n, 4, 3), torch.int32) if s.in_table else None}
+
+    def level(self, level):
+        """Views of level `level` (after that many poolings): edge lists, CSRs, in-edge table, node_loc."""
+        s, loc = self._level_struct(level)
+        out = self._graph_views(s)
+        out['node_loc'] = self._view(loc.value, (out['n_nodes'], 2), torch.int64)
+        return out
+
+    def pooling(self, level):
+        """(cluster int32 [n_level], [dup_map int32 [E_q]] * 4) of the pooling level -> level + 1."""
+        cluster, dup = C.c_void_p(), _lib.VoidP4()
+        call('gunet_plan_pooling', self.handle, level, C.byref(cluster), C.byref(dup))
+        return (self._view(cluster.value, (self.n_nodes[level],), torch.int32),
+                [self._view(dup[q], (self.n_edges[level][q],), torch.int32) for q in range(4)])
+
+    def upsampling(self, level):
+        """(parent int32 [n_level], graph views) of the upsampling level + 1 -> level."""
+        s, parent = QuadGraphStruct(), C.c_void_p()
+        call('gunet_plan_upsampling', self.handle, level, C.byref(s), C.byref(parent))
+        return self._view(parent.value, (self.n_nodes[level],), torch.int32), self._graph_views(s)
+
+
+_unet_cache = OrderedDict()
+
+
+def get_unet_plan(node_loc, edge_index, depth):
+    key = (node_loc.data_ptr(), int(node_loc.shape[0]), _edge_key(edge_index), int(depth))
+    hit = _unet_cache.get(key)
+    if hit is not None:
+        return hit
+    plan = UNetPlan(node_loc, edge_index, depth)
+    plan._keepalive = [node_loc] + list(edge_index)
+    return _remember(_unet_cache, key, plan)
+
+
 _workspaces = {}
 
 
@@ -218,4 +314,19 @@ def workspace(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
+    return buf
+
+
+_model_workspaces = {}
+
+
+def model_workspace(nbytes, device):
+    """Per-device buffer of the whole-model entry point (all intermediates of one forward, skip
+    tensors included); grows to the largest request and is reused in stream order."""
+    key = (device.type, device.index)
+    buf = _model_workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _model_workspaces[key] = None
+        buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        _model_workspaces[key] = buf
     return buf

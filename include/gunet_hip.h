@@ -207,7 +207,7 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
  *   x_out      [B, N, units]
  *   edges_out[q] [B, E_q, u]          (graph['edges'] after the call)
  *   global_out [B, units], or [B, g + units + u] when globt_w == NULL
- * Only units == 128 is implemented. */
+ * units = 128 and 256 are implemented. */
 int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* weights,
                                int32_t batch, const float* x, const float* x_skip, int32_t c_skip,
                                const float* const edges[4], const float* global_in,
@@ -228,6 +228,77 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
                                   const float* global_in, int32_t activation, float* x_out,
                                   float* global_out, void* workspace, size_t workspace_bytes,
                                   gunet_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 2b. The whole model -- models/graph_unet.py:21-84
+ * ------------------------------------------------------------------------ */
+
+#define GUNET_MAX_DEPTH 8
+
+/* Every index structure GraphUNet.call needs for one city graph, owned by the handle and immutable
+ * after creation (shareable across streams and samples): per level l = 0..depth the quadrant graph
+ * with its receiver CSRs and in-edge table, the 2x2 pooling maps l -> l+1
+ * (layers/hybrid_gnn.py:410-447, graph_pooling_2x2 and remove_duplicate_edges, index part) and the
+ * upsampling graph l+1 -> l (:270-280, :336-357).  The reference recomputes all of it with
+ * tf.unique / boolean masks inside every forward.  node_loc int64 [N,2], edge_index[q] int32
+ * [n_edges[q],2]: the level-0 graph (graph dict of models/base_model.py:302-312); the plan keeps its
+ * own copy.  A plan function: allocates device memory (freed by gunet_plan_destroy) and
+ * synchronises the stream. */
+typedef struct gunet_plan gunet_plan;
+int gunet_plan_create(const int64_t* node_loc, int64_t n_nodes, const int32_t* const edge_index[4],
+                      const int64_t n_edges[4], int32_t depth, gunet_plan** plan_out,
+                      gunet_stream_t stream);
+int gunet_plan_destroy(gunet_plan* plan);
+int gunet_plan_depth(const gunet_plan* plan);
+
+/* Views into a plan (device pointers owned by the plan; any output may be NULL).
+ *   level l in 0..depth:  the quadrant graph and node_loc int64 [n_nodes,2] after l poolings;
+ *   pooling l in 0..depth-1: cluster int32 [n_l] (:423 new_node_ids) and, per quadrant, dup_map
+ *                         int32 [E_lq] (edge -> pooled edge, -1 = became a self-loop);
+ *   upsampling l in 0..depth-1: the graph over n_{l+1} + n_l nodes with edges
+ *                         (parent, n_{l+1} + i) and parent int32 [n_l]. */
+int gunet_plan_level(const gunet_plan* plan, int32_t level, gunet_quadgraph* graph_out,
+                     const int64_t** node_loc_out);
+int gunet_plan_pooling(const gunet_plan* plan, int32_t level, const int32_t** cluster_out,
+                       const int32_t* dup_map_out[4]);
+int gunet_plan_upsampling(const gunet_plan* plan, int32_t level, gunet_quadgraph* graph_out,
+                          const int32_t** parent_out);
+
+/* Parameters of GraphUNet (models/graph_unet.py:21-59) in the checkpoint's layout.  The in_layer's
+ * width is down[0].c_in; every later width follows from the layers' own fields, and the forward
+ * checks that they chain as the model wires them. */
+typedef struct gunet_unet_weights {
+  int32_t depth;
+  int32_t c_in;                /* columns of the model input x (104 in the reference) */
+  int32_t out_units;           /* columns of the prediction (96) */
+  const float* in_kernel;      /* in_layer [c_in, down[0].c_in] */
+  const float* in_bias;        /* [down[0].c_in] or NULL */
+  const float* out_kernel;     /* out_model [units of the last layer, out_units] */
+  const float* out_bias;       /* NULL in the reference (use_bias=False, :58) */
+  gunet_gn_weights down[GUNET_MAX_DEPTH];        /* downsampling_layers/i/gcns/0 */
+  gunet_gn_weights bottleneck[2];                /* bottleneck_gcn_1, bottleneck_gcn_2 */
+  gunet_gn_weights up_sampling[GUNET_MAX_DEPTH]; /* upsampling_layers/i/upsampling/gcn */
+  gunet_gn_weights up_gcn[GUNET_MAX_DEPTH][2];   /* upsampling_layers/i/gcns/0..1 */
+} gunet_unet_weights;
+
+/* models/graph_unet.py:61-84 GraphUNet.call (diffuse_graph=False, residual=False, method 'graph',
+ * use_global=True: the configuration the reference trains), for `batch` samples on the plan's graph:
+ *   x [B, N, c_in], edges[q] [B, E_q, down[0].f_e], global_in [B, down[0].g]
+ *   out [B, N, out_units] = out_activation(out_model(...)); GUNET_ACT_RELU fuses the max(pred, 0)
+ *   of models/base_model.py:325
+ *   edges_out (may be NULL, as may its entries): graph['edges'] after the call, [B, E_q, u];
+ *   global_out (may be NULL): graph['global'] after the call, [B, g + units + u of the last layer].
+ * Same kernels in the same order as the per-layer entry points: results are bit-identical to
+ * calling those one by one.  Asynchronous on `stream`; allocates nothing; every intermediate
+ * (skip tensors included) lives in `workspace` (256-byte aligned,
+ * gunet_unet_workspace_bytes(plan, weights, batch) bytes; 0 = the weights do not fit the plan). */
+size_t gunet_unet_workspace_bytes(const gunet_plan* plan, const gunet_unet_weights* weights,
+                                  int32_t batch);
+int gunet_unet_forward_f32(const gunet_plan* plan, const gunet_unet_weights* weights, int32_t batch,
+                           const float* x, const float* const edges[4], const float* global_in,
+                           int32_t activation, int32_t out_activation, float* out,
+                           float* const edges_out[4], float* global_out, void* workspace,
+                           size_t workspace_bytes, gunet_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3. Either side of the model -- graph construction, input assembly (models/base_model.py:274-312),

@@ -1,0 +1,180 @@
+"""The whole-model entry points: gunet_plan_* (every level's index structures behind one handle)
+and gunet_unet_forward_f32 (GraphUNet.call as one library call).
+
+  * the plan's levels, pooling maps and upsampling graphs against the oracle -- bit-exact;
+  * the one-call forward against the oracle (fp32: max|got - want| / max|want| <= 1e-5) and
+    against the layer-by-layer path through the per-layer entry points -- bit-identical;
+  * argument checking: weights that do not chain, workspace too small."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import gunet_amd
+    return gunet_amd
+
+
+def _model(amd, W, depth=3, units=32, **kw):
+    model = amd.GraphUNet(units, out_units=96, depth=depth, activation='relu', layer_type='geo_quadrant_gcn',
+                          use_bias=True, use_global=True, output_activation=None, **kw)
+    return model.load_weights(W, 'cuda')
+
+
+@pytest.mark.parametrize('size', [(12, 16, 0.6), (40, 52, 0.45), (97, 83, 0.4)])
+def test_plan_levels_bit_exact(amd, oracle, size):
+    from gunet_amd import plan
+    node_loc, ei, d, _ = oracle.synth_road_graph(*size, 3)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    depth = 3
+    up = plan.UNetPlan(to_dev(node_loc, torch.int64), [to_dev(q, torch.int32) for q in quads], depth)
+    loc, lists = node_loc, list(quads)
+    for level in range(depth + 1):
+        got = up.level(level)
+        assert got['n_nodes'] == loc.shape[0] == up.n_nodes[level]
+        assert np.array_equal(got['node_loc'].cpu().numpy(), loc)
+        for q in range(4):
+            assert np.array_equal(got['edge_index'][q].cpu().numpy(), lists[q]), (level, q)
+            # receiver CSR: rows ascending in the reference's edge order
+            rowptr, perm = got['rowptr'][q].cpu().numpy(), got['perm'][q].cpu().numpy()
+            order = np.argsort(lists[q][:, 1], kind='stable') if lists[q].shape[0] else np.zeros(0, np.int64)
+            assert np.array_equal(perm[:lists[q].shape[0]], order)
+            assert np.array_equal(rowptr, np.concatenate(([0], np.cumsum(np.bincount(lists[q][:, 1], minlength=loc.shape[0])))))
+        if level == depth:
+            break
+        # pooling level -> level + 1 (hybrid_gnn.py:415-434)
+        ids, n_pooled = oracle.cluster_ids_2x2(loc)
+        cluster, dup_map = up.pooling(level)
+        assert np.array_equal(cluster.cpu().numpy(), ids)
+        coarse_loc = oracle.unsorted_segment_min(loc // 2, ids, n_pooled)
+        new_lists = []
+        for q in range(4):
+            feats = np.arange(lists[q].shape[0], dtype=np.float32)[:, None]
+            new_e, _ = oracle.remove_duplicate_edges(ids[lists[q]], np.int64(loc.shape[0]), feats)
+            new_lists.append(new_e)
+            dm = dup_map[q].cpu().numpy()
+            relabelled = ids[lists[q]]
+            alive = dm >= 0
+            assert np.array_equal(alive, relabelled[:, 0] != relabelled[:, 1])
+            assert np.array_equal(new_e[dm[alive]], relabelled[alive])
+        # upsampling level + 1 -> level (hybrid_gnn.py:336-357)
+        parent, upg = up.upsampling(level)
+        want_parent, want_lists = oracle.upsample_edges(coarse_loc, loc)
+        assert np.array_equal(parent.cpu().numpy(), want_parent)
+        assert upg['n_nodes'] == n_pooled + loc.shape[0]
+        for q in range(4):
+            assert np.array_equal(upg['edge_index'][q].cpu().numpy(), want_lists[q])
+        loc, lists = coarse_loc, new_lists
+
+
+# (18, 50): more than twice as wide as high, where the reference's cell ids collide and some fine
+# nodes get no upsampling edge -- the forward then runs that layer on [x ; zeros] as written
+@pytest.mark.parametrize('size,batch', [((12, 16, 0.6), 1), ((40, 52, 0.45), 3), ((18, 50, 0.55), 2)])
+def test_unet_forward_one_call(amd, oracle, size, batch):
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    assert model._native_ok()
+    x, graph, _ = make_case(oracle, *size)
+    node_loc, quads = graph['node_loc'], graph['edge_index']
+    enc = oracle.synth_street_encoding(node_loc.shape[0], 5)
+    xs, graphs = [], []
+    for b in range(batch):
+        sn, te, wd = oracle.synth_sample(node_loc, quads, 300 + b, time_idx=5 * b, weekday=b)
+        xb, gb = oracle.assemble_inputs(sn, enc, quads, node_loc, te, wd)
+        xs.append(xb)
+        graphs.append(gb)
+
+    def dev_graph():
+        g = graph_to_dev(graphs[0])
+        g['edge_index'], g['node_loc'] = shared['edge_index'], shared['node_loc']
+        g['edges'] = [torch.stack([to_dev(gr['edges'][q]) for gr in graphs]) for q in range(4)]
+        g['global'] = torch.cat([to_dev(gr['global']) for gr in graphs], dim=0)
+        return g
+
+    shared = graph_to_dev(graphs[0])
+    xd = torch.stack([to_dev(v) for v in xs])
+    got_y, got_g = model(xd, dev_graph())
+    for b in range(batch):
+        want_y, want_g = oracle.graph_unet_forward(xs[b], copy_graph(graphs[b]), W)
+        assert rel_err(got_y[b].cpu().numpy(), want_y) <= TOL
+        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
+        for q in range(4):
+            assert rel_err(got_g['edges'][q][b].cpu().numpy(), want_g['edges'][q]) <= TOL
+            assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), want_g['edge_index'][q])
+    # the layer objects, one library call per layer: same kernels, same order
+    model.native_forward = False
+    assert not model._native_ok()
+    ref_y, ref_g = model(xd, dev_graph())
+    assert torch.equal(got_y, ref_y)
+    assert torch.equal(got_g['global'], ref_g['global'])
+    for q in range(4):
+        assert torch.equal(got_g['edges'][q], ref_g['edges'][q])
+    # predict() = forward + max(pred, 0) fused into the last GEMM
+    model.native_forward = True
+    assert torch.equal(model.predict(xd, dev_graph()), torch.clamp_min(got_y, 0))
+    # 2-D single-sample form
+    y1, g1 = model(xd[0], {**dev_graph(), 'edges': [to_dev(graphs[0]['edges'][q]) for q in range(4)],
+                           'global': to_dev(graphs[0]['global'])})
+    assert y1.dim() == 2 and g1['edges'][0].dim() == 2
+    assert rel_err(y1.cpu().numpy(), oracle.graph_unet_forward(xs[0], copy_graph(graphs[0]), W)[0]) <= TOL
+
+
+def test_unet_forward_mixed_widths(amd, oracle):
+    """units=64, depth=3: block widths 128, 128, 256 on the way down (hybrid widths in one model)."""
+    shapes = oracle.graph_unet_shapes_for(64, depth=3)
+    W = oracle.make_weights(shapes, 2)
+    model = _model(amd, W, units=64)
+    x, graph, _ = make_case(oracle, 30, 26, 0.55)
+    want_y, _ = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    got_y, _ = model(to_dev(x), graph_to_dev(graph))
+    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
+    model.native_forward = False
+    ref_y, _ = model(to_dev(x), graph_to_dev(graph))
+    assert torch.equal(got_y, ref_y)
+
+
+def test_unet_forward_errors(amd, oracle):
+    from gunet_amd import _lib, plan
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    x, graph, _ = make_case(oracle, 12, 16, 0.6)
+    g = graph_to_dev(graph)
+    xd = to_dev(x)
+    model(xd, dict(g))
+    up = plan.get_unet_plan(g['node_loc'], g['edge_index'], 3)
+    ws = model._native_struct
+    need = _lib.lib.gunet_unet_workspace_bytes(up.handle, C.byref(ws), 1)
+    assert need > 0
+    out = torch.empty((1, x.shape[0], 96), device='cuda')
+    buf = torch.empty(need + 512, dtype=torch.uint8, device='cuda')
+    base = (buf.data_ptr() + 255) // 256 * 256
+    feats = _lib.ptr4([e.unsqueeze(0) for e in g['edges']])
+    args = lambda nbytes: (up.handle, C.byref(ws), 1, _lib.ptr(xd), C.byref(feats), _lib.ptr(g['global']), 1, 0,
+                           _lib.ptr(out), None, None, C.c_void_p(base), nbytes, None)
+    assert _lib.lib.gunet_unet_forward_f32(*args(need)) == 0
+    torch.cuda.synchronize()
+    assert _lib.lib.gunet_unet_forward_f32(*args(need - 1024)) == -3          # GUNET_ERR_WORKSPACE
+    assert 'workspace' in _lib.last_error()
+    # a plan of another depth, and weights whose widths do not chain
+    up2 = plan.UNetPlan(g['node_loc'], g['edge_index'], 2)
+    assert _lib.lib.gunet_unet_workspace_bytes(up2.handle, C.byref(ws), 1) == 0
+    assert 'depth' in _lib.last_error()
+    saved = ws.down[1].c_in
+    ws.down[1].c_in = 96
+    try:
+        assert _lib.lib.gunet_unet_forward_f32(*args(need)) == -1             # GUNET_ERR_INVALID
+        assert 'down[1]' in _lib.last_error()
+    finally:
+        ws.down[1].c_in = saved
+    with pytest.raises(ValueError):
+        model(xd[:-1], dict(g))
