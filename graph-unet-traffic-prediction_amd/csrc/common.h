@@ -115,4 +115,10 @@ int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, hipStream_t s
 int csr_from_keys(const int32_t* keys, int key_stride, int key_offset, int64_t n,
                   int32_t n_segments, int32_t* rowptr, int32_t* perm, hipStream_t stream);
 
+// Up to five row-wise segment maxima (src[i] [B, n_src[i], width[i]] -> out[i] [B, n_seg[i], width[i]]
+// over the CSR rowptr[i] / perm[i]) in one launch: the node and edge features of a 2x2 pooling step.
+int pool_max_multi(int n_jobs, const float* const* src, const int64_t* n_src, const int* width,
+                   const int32_t* const* rowptr, const int32_t* const* perm, const int64_t* n_seg, float* const* out,
+                   int32_t batch, hipStream_t stream);
+
 }  // namespace gunet

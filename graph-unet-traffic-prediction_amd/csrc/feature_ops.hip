@@ -113,6 +113,47 @@ int launch_segment_reduce(const float* src, int64_t n_src, int32_t width, const 
   return GUNET_OK;
 }
 
+// The five segment maxima of one 2x2 pooling step (node features and the four edge-feature sets,
+// layers/hybrid_gnn.py:427, :401) as one launch: consecutive block ranges serve the jobs, each
+// thread does exactly what k_segment_reduce<4, true> does for its element.
+constexpr int kPoolJobs = 5;
+struct PoolJobs {
+  const float* src[kPoolJobs];
+  float* out[kPoolJobs];
+  const int32_t* rowptr[kPoolJobs];
+  const int32_t* perm[kPoolJobs];
+  int64_t n_src[kPoolJobs];
+  int64_t n_seg[kPoolJobs];
+  int width[kPoolJobs];
+  unsigned block_end[kPoolJobs];   // running total of the jobs' block counts
+};
+
+__global__ void k_pool_max(PoolJobs j) {
+  int job = 0;
+  while (job < kPoolJobs - 1 && blockIdx.x >= j.block_end[job]) ++job;
+  const unsigned block = blockIdx.x - (job > 0 ? j.block_end[job - 1] : 0u);
+  const int width = j.width[job], wv = width / 4;
+  const int64_t n_seg = j.n_seg[job];
+  const int64_t idx = static_cast<int64_t>(block) * blockDim.x + threadIdx.x;
+  if (idx >= n_seg * wv) return;
+  const int64_t seg = idx / wv;
+  const int c = static_cast<int>(idx % wv) * 4;
+  const int64_t b = blockIdx.y;
+  const float* s = j.src[job] + b * j.n_src[job] * width + c;
+  const int32_t* rowptr = j.rowptr[job];
+  const int32_t* perm = j.perm[job];
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  float4 acc = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+  for (int p = beg; p < end; ++p) {
+    const float4 v = *reinterpret_cast<const float4*>(s + static_cast<int64_t>(perm[p]) * width);
+    acc.x = fmaxf(acc.x, v.x);
+    acc.y = fmaxf(acc.y, v.y);
+    acc.z = fmaxf(acc.z, v.z);
+    acc.w = fmaxf(acc.w, v.w);
+  }
+  *reinterpret_cast<float4*>(j.out[job] + (b * n_seg + seg) * width + c) = acc;
+}
+
 // ---------------------------------------------------------------- GEMM on fp32 MFMA
 
 // out[b, map(r), :] = act( sum_s A_s[b, r, :] @ W_s + bias[b] ),  r < n_rows, for up to three operand
@@ -166,8 +207,9 @@ constexpr int kRowGroup = 32;   // rows of one wave = rows of one column-sum par
 // Only the weight tile goes through LDS (double-buffered, one barrier per K tile); the next A
 // tile is prefetched in registers.  Epilogue: bias, activation, optional row scatter, and the
 // column sums of every wave's 32 rows (fixed order: 16 rows per lane, then the two half-waves).
+// `bx`: this workgroup's row tile within the problem `g`.
 template <int NT>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const int bx) {
   constexpr int BN = 32 * NT;
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BN];
   __shared__ __attribute__((aligned(16))) float Stage[4][16 * 32];   // epilogue: one per wave
@@ -176,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.y;
-  const int row0 = blockIdx.x * kBM;
+  const int row0 = bx * kBM;
   const int my_row = row0 + 32 * wave + li;
   const bool row_ok = my_row < g.n_rows;
 
@@ -327,9 +369,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
     __syncthreads();
     if (tid < BN) {
       const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + bx) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
+  gemm_f32_tile<NT>(g, blockIdx.x);
+}
+
+// Up to four independent problems of the same column-tile count in one grid (the four quadrant
+// GEMMs of the upsampling layer): consecutive block ranges serve the problems.
+constexpr int kGemmGroup = 4;
+struct GemmGroup {
+  GemmArgs p[kGemmGroup];
+  unsigned block_end[kGemmGroup];   // running total of the problems' row tiles
+};
+
+template <int NT>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32_group(GemmGroup gg) {
+  int i = 0;
+  while (i < kGemmGroup - 1 && blockIdx.x >= gg.block_end[i]) ++i;
+  gemm_f32_tile<NT>(gg.p[i], static_cast<int>(blockIdx.x - (i > 0 ? gg.block_end[i - 1] : 0u)));
 }
 
 // Weights-resident variant (the weight matrix must fit LDS: 32 * NKT * 32 * NT floats): a workgroup
@@ -1088,6 +1150,46 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
   return GUNET_OK;
 }
 
+// Several problems with the same column-tile count and batch as one launch of the tiled float32
+// kernel (the bf16 / split modes, and single problems, go through launch_gemm one by one).  The
+// caller has set colsum_tiles / colsum_tile0 / colsum_ld / out_rows.
+int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wpack, hipStream_t stream) {
+  int live[kGemmGroup], n_live = 0;
+  for (int i = 0; i < n; ++i)
+    if (gs[i].n_rows > 0) live[n_live++] = i;
+  bool tiled = n_live > 1 && n_live <= kGemmGroup && batch > 0 && !takes_split(wpack);
+  for (int i = 0; i < n_live && tiled; ++i) tiled = !resident_ok(gs[live[i]], nt, batch);
+  if (!tiled) {
+    for (int i = 0; i < n_live; ++i) GUNET_TRY(launch_gemm(gs[live[i]], nt, batch, wpack, stream));
+    return GUNET_OK;
+  }
+  GemmGroup gg = {};
+  unsigned blocks = 0;
+  double flops = 0.0;
+  for (int i = 0; i < kGemmGroup; ++i) {
+    if (i < n_live) {
+      gg.p[i] = gs[live[i]];
+      GemmArgs& g = gg.p[i];
+      if (g.out_rows == 0) g.out_rows = g.n_rows;
+      if (g.colsum_ld == 0) g.colsum_ld = 32 * nt;
+      blocks += static_cast<unsigned>(ceil_div(g.n_rows, kBM));
+      for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
+    }
+    gg.block_end[i] = blocks;
+  }
+  dim3 grid(blocks, static_cast<unsigned>(batch));
+  ProfScope prof(kProfGemmTiled, stream, flops);
+  switch (nt) {
+    case 1: k_gemm_f32_group<1><<<grid, kThreads, 0, stream>>>(gg); break;
+    case 2: k_gemm_f32_group<2><<<grid, kThreads, 0, stream>>>(gg); break;
+    case 3: k_gemm_f32_group<3><<<grid, kThreads, 0, stream>>>(gg); break;
+    case 4: k_gemm_f32_group<4><<<grid, kThreads, 0, stream>>>(gg); break;
+    default: set_error("launch_gemm_group: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+  }
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
 // ---------------------------------------------------------------- GeoQuadrantGCN pieces
 //
 // Kernels of one GN layer, templated on UT = units / 128: U = 128*UT output columns per node,
@@ -1807,6 +1909,47 @@ int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float
 }
 
 }  // namespace
+
+int pool_max_multi(int n_jobs, const float* const* src, const int64_t* n_src, const int* width,
+                   const int32_t* const* rowptr, const int32_t* const* perm, const int64_t* n_seg, float* const* out,
+                   int32_t batch, hipStream_t stream) {
+  GUNET_REQUIRE(n_jobs >= 0 && n_jobs <= kPoolJobs, "pool_max_multi: %d jobs", n_jobs);
+  bool vec = true;
+  for (int i = 0; i < n_jobs; ++i)
+    vec = vec && width[i] % 4 == 0 && reinterpret_cast<uintptr_t>(src[i]) % 16 == 0 &&
+          reinterpret_cast<uintptr_t>(out[i]) % 16 == 0;
+  if (!vec) {
+    for (int i = 0; i < n_jobs; ++i)
+      GUNET_TRY(launch_segment_reduce<true>(src[i], n_src[i], width[i], rowptr[i], perm[i], n_seg[i], batch, 1.0f,
+                                            out[i], stream));
+    return GUNET_OK;
+  }
+  PoolJobs j = {};
+  unsigned blocks = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < kPoolJobs; ++i) {
+    if (i < n_jobs && batch > 0) {
+      j.src[i] = src[i];
+      j.out[i] = out[i];
+      j.rowptr[i] = rowptr[i];
+      j.perm[i] = perm[i];
+      j.n_src[i] = n_src[i];
+      j.n_seg[i] = n_seg[i];
+      j.width[i] = width[i];
+      blocks += static_cast<unsigned>(ceil_div(n_seg[i] * (width[i] / 4), kThreads));
+      bytes += static_cast<double>(batch) * (4.0 * width[i] * (n_src[i] + n_seg[i]) + 4.0 * (n_src[i] + n_seg[i]));
+    } else {
+      j.width[i] = 4;
+    }
+    j.block_end[i] = blocks;
+  }
+  if (blocks == 0) return GUNET_OK;
+  ProfScope prof(kProfSegment, stream, bytes);
+  k_pool_max<<<dim3(blocks, static_cast<unsigned>(batch)), kThreads, 0, stream>>>(j);
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
 }  // namespace gunet
 
 using namespace gunet;
@@ -2162,11 +2305,14 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     auto w_of = [&](int, int col) { return w->node_w + col; };
     GUNET_TRY(launch_gemm_columns(gc, U, batch, ws.gbias, U, nullptr, ws.npart, w_of, ws.wpack, stream));
   }
-  for (int q = 0; q < 4; ++q) {
-    if (graph->n_edges[q] == 0) continue;
-    gq[q].colsum_tiles = tiles_total;
-    auto w_of = [&](int, int col) { return w->node_w + static_cast<int64_t>(w->c_in + u * q) * U + col; };
-    GUNET_TRY(launch_gemm_columns(gq[q], U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
+  for (int col0 = 0; col0 < U; col0 += 128) {   // the four quadrants' problems share a launch
+    GemmArgs blockq[4];
+    for (int q = 0; q < 4; ++q) {
+      gq[q].colsum_tiles = tiles_total;
+      auto w_of = [&](int, int col) { return w->node_w + static_cast<int64_t>(w->c_in + u * q) * U + col; };
+      blockq[q] = columns_block(gq[q], U, col0, 4, ws.gbias, U, x_out, ws.npart, w_of);
+    }
+    GUNET_TRY(launch_gemm_group(blockq, 4, 4, batch, ws.wpack, stream));
   }
   return launch_global_update(p, ut, global_in, tiles_total, relu, batch, ws, global_out, stream);
 }

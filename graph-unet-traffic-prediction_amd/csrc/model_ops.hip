@@ -441,11 +441,24 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
                                          mb.tmp_x[0], mb.tmp_e[0].q, mb.skip_g[l + 1], mb.layer_ws, mb.layer_ws_bytes,
                                          stream));
     cur_g = mb.skip_g[l + 1];
-    GUNET_TRY(gunet_segment_max_f32(mb.tmp_x[0], L.n_nodes, gw.units, pool.cluster_rowptr, pool.cluster_perm,
-                                    C.n_nodes, batch, mb.skip_x[l + 1], stream));
-    for (int q = 0; q < 4; ++q)
-      GUNET_TRY(gunet_segment_max_f32(mb.tmp_e[0].q[q], L.n_edges[q], gw.units / 4, pool.dup_rowptr[q], pool.dup_perm[q],
-                                      C.n_edges[q], batch, mb.skip_e[l + 1].q[q], stream));
+    {  // graph_pooling_2x2 (hybrid_gnn.py:427, :401): node features and the four edge-feature sets
+      const float* src[5] = {mb.tmp_x[0]};
+      float* dst[5] = {mb.skip_x[l + 1]};
+      const int32_t* rowptr[5] = {pool.cluster_rowptr};
+      const int32_t* perm[5] = {pool.cluster_perm};
+      int64_t n_src[5] = {L.n_nodes}, n_seg[5] = {C.n_nodes};
+      int width[5] = {gw.units};
+      for (int q = 0; q < 4; ++q) {
+        src[1 + q] = mb.tmp_e[0].q[q];
+        dst[1 + q] = mb.skip_e[l + 1].q[q];
+        rowptr[1 + q] = pool.dup_rowptr[q];
+        perm[1 + q] = pool.dup_perm[q];
+        n_src[1 + q] = L.n_edges[q];
+        n_seg[1 + q] = C.n_edges[q];
+        width[1 + q] = gw.units / 4;
+      }
+      GUNET_TRY(pool_max_multi(5, src, n_src, width, rowptr, perm, n_seg, dst, batch, stream));
+    }
   }
 
   // bottleneck (:73-74)

@@ -35,7 +35,10 @@ for B in (1, 2, 8):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
+    model.native_forward = False
+    layerwise = timeit(lambda: model.predict(xt, dict(g)))
+    model.native_forward = True
     eager = timeit(lambda: model.predict(xt, dict(g)))
     cap = gunet_amd.CapturedForward(model, xt, g)
     replay = timeit(lambda: cap(xt))
-    print(f'B={B}: eager {eager:.3f} ms ({B / eager * 1e3:.0f} samples/s), graph replay {replay:.3f} ms ({B / replay * 1e3:.0f} samples/s)', flush=True)
+    print(f'B={B}: layer objects {layerwise:.3f} ms, one call {eager:.3f} ms ({B / eager * 1e3:.0f} samples/s), graph replay {replay:.3f} ms ({B / replay * 1e3:.0f} samples/s)', flush=True)
