@@ -52,7 +52,7 @@ KERNEL_OF_CLASS = {'gemm_tiled': 'k_gemm_f32', 'gemm_resident_k128': 'k_gemm_res
                    'gemm_resident_k256': 'k_gemm_resident<*, 8>', 'gemm_resident_k384': 'k_gemm_resident<*, 12>',
                    'gemm_resident_bf16': 'k_gemm_resident<.., bf16>', 'gemm_split': 'k_gemm_split', 'edge_mlp': 'k_edge_mlp',
                    'aggregate': 'k_aggregate', 'segment_reduce': 'k_segment_reduce', 'layer_prologue': 'k_layer_prologue',
-                   'global_update': 'k_global_update', 'gather_rows': 'k_gather_rows', 'dense_naive': 'k_dense_naive'}
+                   'global_update': 'k_global_update', 'global_bridge': 'k_global_bridge', 'gather_rows': 'k_gather_rows', 'dense_naive': 'k_dense_naive'}
 
 
 def measured_traffic(kernel, args):

@@ -62,7 +62,7 @@ class UNetWeightsStruct(C.Structure):
 
 VoidP4 = C.c_void_p * 4
 I64x4 = C.c_int64 * 4
-PROF_CLASSES = 13
+PROF_CLASSES = 14
 F64xP = C.c_double * PROF_CLASSES
 I64xP = C.c_int64 * PROF_CLASSES
 

@@ -82,6 +82,7 @@ enum ProfClass {
   kProfGemmSplit,
   kProfGemmRes384,
   kProfGemmResBf16,
+  kProfBridge,
   kProfCount
 };
 static_assert(kProfCount == GUNET_PROF_CLASSES, "profiler class table out of step with the header");
@@ -114,6 +115,28 @@ int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, hipStream_t s
 // keys[i * key_stride + key_offset] is the key of element i; negative keys are skipped.
 int csr_from_keys(const int32_t* keys, int key_stride, int key_offset, int64_t n,
                   int32_t n_segments, int32_t* rowptr, int32_t* perm, hipStream_t stream);
+
+// The GN layer entry points with their first kernel (the prologue: folded biases from the input
+// global) and / or their last one (the global update) left out, for a caller that runs consecutive
+// layers and joins each layer's global update with the next layer's prologue (gn_bridge).
+// n_partials_out receives the number of column-sum rows per sample the node MLP wrote, which the
+// global update (or gn_bridge) of that layer needs.  flags = 0 is the public entry point.
+constexpr int kGnSkipPrologue = 1;
+constexpr int kGnSkipGlobalUpdate = 2;
+int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch, const float* x,
+                 const float* x_skip, int32_t c_skip, const float* const edges[4], const float* global_in,
+                 int32_t activation, float* x_out, float* const edges_out[4], float* global_out, void* workspace,
+                 size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream);
+int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w, int32_t batch,
+                    const float* x, const float* global_in, int32_t activation, float* x_out, float* global_out,
+                    void* workspace, size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream);
+// Global update of layer `cur` (input global global_in, result to global_out) and prologue of layer
+// `next`, whose input global is that result, or [result | extra] (then also written to cat_out),
+// in one launch.  Both layers use the same workspace.
+int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int n_partials, const float* global_in,
+              float* global_out, const float* extra, int extra_width, float* cat_out, const gunet_quadgraph* next_graph,
+              const gunet_gn_weights* next, int next_fold_receiver, int32_t batch, int32_t activation, void* workspace,
+              size_t workspace_bytes, hipStream_t stream);
 
 // Up to five row-wise segment maxima (src[i] [B, n_src[i], width[i]] -> out[i] [B, n_seg[i], width[i]]
 // over the CSR rowptr[i] / perm[i]) in one launch: the node and edge features of a 2x2 pooling step.

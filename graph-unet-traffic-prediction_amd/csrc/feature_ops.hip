@@ -1259,24 +1259,17 @@ __device__ inline float combine_rows(const float* part, int n, int ld, int col) 
 // and the four node-embedding biases laid side by side.  Everything that does not depend on the
 // chain (the node-MLP bias, the constant receiver term of the upsampling form, and the weights the
 // later chain steps need) is fetched first, so the chain itself only waits on LDS.
+// `gl` (LDS, [g]) holds the sample's global vector; it may still be in the making when the body
+// starts (the first barrier below covers it).  `part` is 4096 floats of LDS scratch, `gq` [4][u].
 template <int UT>
-__global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
-                                                                  const float* __restrict__ global_in,
-                                                                  int relu, int fold_receiver,
-                                                                  float* __restrict__ nbias,
-                                                                  float* __restrict__ ebias,
-                                                                  float* __restrict__ gbias) {
+__device__ __forceinline__ void prologue_body(const LayerPtrs& p, const float* gl, int relu, int fold_receiver,
+                                              int64_t b, float* part, float* gq, float* __restrict__ nbias,
+                                              float* __restrict__ ebias, float* __restrict__ gbias) {
   constexpr int U = 128 * UT, u = 32 * UT;
   constexpr int QC = U / 4, S = kSmallThreads / QC;     // matvec: column quads x row subsets
   constexpr int CG = kSmallThreads / u, CR = u / CG;    // chain: CG row groups, CR rows each (u -> u steps)
   constexpr int EG = kSmallThreads / U, ER = u / EG;    // edge bias: EG row groups, ER rows each
-  extern __shared__ __attribute__((aligned(16))) float sh[];
-  float* part = sh;                      // 4096 floats, reused by every reduction
-  float* gl = part + 4096;               // [g]
-  float* gq = gl + p.g;                  // [4][u]
   const int tid = threadIdx.x;
-  const int64_t b = blockIdx.x;
-  for (int k = tid; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
 
   const int cgrp = tid / u, ccol = tid % u;
   float wq[3][CR];
@@ -1356,6 +1349,22 @@ __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
   }
   __syncthreads();
   if (tid < U) ebias[b * U + tid] = combine_rows(part, EG, U, tid) + e_const;
+}
+
+template <int UT>
+__global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
+                                                                  const float* __restrict__ global_in,
+                                                                  int relu, int fold_receiver,
+                                                                  float* __restrict__ nbias,
+                                                                  float* __restrict__ ebias,
+                                                                  float* __restrict__ gbias) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* part = sh;                      // 4096 floats, reused by every reduction
+  float* gl = part + 4096;               // [g]
+  float* gq = gl + p.g;                  // [4][u]
+  const int64_t b = blockIdx.x;
+  for (int k = threadIdx.x; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
+  prologue_body<UT>(p, gl, relu, fold_receiver, b, part, gq, nbias, ebias, gbias);
 }
 
 struct EdgeArgs {
@@ -1595,23 +1604,19 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
 // Per sample: finish the node / edge column sums (fp64 accumulation over the per-tile partials:
 // the thread subsets take tiles sub, sub + S, ... with float4 loads, the subsets are then added in
 // order), scale them and apply the global transform (hybrid_gnn.py:130-135).
+// LDS: dpart 4096 doubles, part 4096 floats, gin [g + U + u] whose first g entries the caller
+// fills with the layer's input global (the first barrier below covers that).  The new global goes
+// to global_out and, when `keep` is not null, also to keep[0 .. width of the new global) in LDS.
 template <int UT>
-__global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
-                                                                 const float* __restrict__ global_in,
-                                                                 const float* __restrict__ npart, int n_nblk,
-                                                                 const float* __restrict__ epart, int n_eblk,
-                                                                 int relu, float* __restrict__ global_out) {
+__device__ __forceinline__ void global_update_body(const LayerPtrs& p, const float* __restrict__ npart, int n_nblk,
+                                                   const float* __restrict__ epart, int n_eblk, int relu, int64_t b,
+                                                   double* dpart, float* part, float* gin,
+                                                   float* __restrict__ global_out, float* keep) {
   constexpr int U = 128 * UT, u = 32 * UT;
   constexpr int QC = U / 4, S = kSmallThreads / QC;
   constexpr int EG = kSmallThreads / U;
-  extern __shared__ __attribute__((aligned(16))) float gsh[];
-  double* dpart = reinterpret_cast<double*>(gsh);          // 4096 doubles
-  float* part = reinterpret_cast<float*>(dpart + 4096);    // 4096 floats
-  float* gin = part + 4096;                                // [g + U + u]
   const int tid = threadIdx.x;
   const int sub = tid / QC, cq = tid % QC;
-  const int64_t b = blockIdx.x;
-  for (int k = tid; k < p.g; k += blockDim.x) gin[k] = global_in[b * p.g + k];
   {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const float4* src = reinterpret_cast<const float4*>(npart + b * n_nblk * static_cast<int64_t>(U)) + cq;
@@ -1678,11 +1683,64 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
     if (tid < U) {
       float t = combine_rows(part, S, U, tid);
       if (p.globt_b) t += p.globt_b[tid];
-      global_out[b * U + tid] = activate(t, relu);
+      t = activate(t, relu);
+      global_out[b * U + tid] = t;
+      if (keep) keep[tid] = t;
     }
   } else {
-    for (int k = tid; k < kin; k += blockDim.x) global_out[b * kin + k] = gin[k];
+    for (int k = tid; k < kin; k += blockDim.x) {
+      global_out[b * kin + k] = gin[k];
+      if (keep) keep[k] = gin[k];
+    }
   }
+}
+
+template <int UT>
+__global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
+                                                                 const float* __restrict__ global_in,
+                                                                 const float* __restrict__ npart, int n_nblk,
+                                                                 const float* __restrict__ epart, int n_eblk,
+                                                                 int relu, float* __restrict__ global_out) {
+  extern __shared__ __attribute__((aligned(16))) float gsh[];
+  double* dpart = reinterpret_cast<double*>(gsh);          // 4096 doubles
+  float* part = reinterpret_cast<float*>(dpart + 4096);    // 4096 floats
+  float* gin = part + 4096;                                // [g + U + u]
+  const int64_t b = blockIdx.x;
+  for (int k = threadIdx.x; k < p.g; k += blockDim.x) gin[k] = global_in[b * p.g + k];
+  global_update_body<UT>(p, npart, n_nblk, epart, n_eblk, relu, b, dpart, part, gin, global_out, nullptr);
+}
+
+// global update of one layer and prologue of the next in one launch (the new global stays in LDS):
+// between two consecutive GN layers of a model nothing else depends on either.  `extra` (may be
+// null) is appended to the new global to form the next layer's input global -- the
+// [global | target global] of the upsampling layer (hybrid_gnn.py:375) -- which then also goes to
+// cat_out.
+template <int UTC, int UTN>
+__global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, const float* __restrict__ global_in,
+                                                                 const float* __restrict__ npart, int n_nblk,
+                                                                 const float* __restrict__ epart, int n_eblk, int relu,
+                                                                 float* __restrict__ global_out,
+                                                                 const float* __restrict__ extra, int extra_width,
+                                                                 float* __restrict__ cat_out, LayerPtrs pn,
+                                                                 int fold_receiver, float* __restrict__ nbias,
+                                                                 float* __restrict__ ebias, float* __restrict__ gbias) {
+  extern __shared__ __attribute__((aligned(16))) float bsh[];
+  double* dpart = reinterpret_cast<double*>(bsh);          // 4096 doubles
+  float* part = reinterpret_cast<float*>(dpart + 4096);    // 4096 floats
+  float* gin = part + 4096;                                // [g + U + u] of the finished layer
+  float* gl = gin + pc.g + 160 * UTC;                      // [g] of the next layer
+  float* gq = gl + pn.g;                                   // [4][u] of the next layer
+  const int64_t b = blockIdx.x;
+  for (int k = threadIdx.x; k < pc.g; k += blockDim.x) gin[k] = global_in[b * pc.g + k];
+  global_update_body<UTC>(pc, npart, n_nblk, epart, n_eblk, relu, b, dpart, part, gin, global_out, gl);
+  if (extra != nullptr) {
+    const int w0 = pn.g - extra_width;   // width of the new global
+    for (int k = threadIdx.x; k < extra_width; k += blockDim.x) gl[w0 + k] = extra[b * extra_width + k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < pn.g; k += blockDim.x) cat_out[b * pn.g + k] = gl[k];
+  }
+  __syncthreads();   // `part` is free again and gl complete
+  prologue_body<UTN>(pn, gl, relu, fold_receiver, b, part, gq, nbias, ebias, gbias);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1715,11 +1773,13 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int unit
     off = align_up(off + floats * sizeof(float), 256);
     return p;
   };
+  // the folded biases come first, at offsets that depend on the batch only: the kernel that finishes
+  // one layer's global and prepares the next layer's biases works on two layouts at once
+  ws.nbias = take(128 * kMaxUT);
+  ws.ebias = take(bsz * 128 * kMaxUT);
+  ws.gbias = take(bsz * 128 * kMaxUT);
   ws.xq = take(bsz * n * U);
   ws.agg = take(bsz * n * U);
-  ws.nbias = take(U);
-  ws.ebias = take(bsz * U);
-  ws.gbias = take(bsz * U);
   ws.npart = take(bsz * (ws.n_nblk + 5) * U);
   ws.epart = take(bsz * 4 * ws.n_eblk * u);
   ws.wpack = take(wpack_bytes((kMaxCin + 128 * kMaxUT) / kBK + 2, 4) / sizeof(float));
@@ -1807,6 +1867,22 @@ int launch_global_update(const LayerPtrs& p, int ut, const float* global_in, int
   else
     k_global_update<2><<<batch, kSmallThreads, lds, stream>>>(p, global_in, ws.npart, n_nblk, ws.epart,
                                                                 ws.n_eblk, relu, global_out);
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+template <int UTC>
+int launch_bridge_utc(const LayerPtrs& pc, const LayerPtrs& pn, int utn, size_t lds, int32_t batch, const float* global_in,
+                      int n_nblk, const LayerWorkspace& wc, int relu, float* global_out, const float* extra,
+                      int extra_width, float* cat_out, int fold_receiver, const LayerWorkspace& wn, hipStream_t stream) {
+  if (utn == 1)
+    k_global_bridge<UTC, 1><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, wc.n_eblk,
+                                                                    relu, global_out, extra, extra_width, cat_out, pn,
+                                                                    fold_receiver, wn.nbias, wn.ebias, wn.gbias);
+  else
+    k_global_bridge<UTC, 2><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, wc.n_eblk,
+                                                                    relu, global_out, extra, extra_width, cat_out, pn,
+                                                                    fold_receiver, wn.nbias, wn.ebias, wn.gbias);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
@@ -2077,11 +2153,32 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
                                const float* x, const float* x_skip, int32_t c_skip,
                                const float* const edges[4], const float* global_in, int32_t activation,
                                float* x_out, float* const edges_out[4], float* global_out,
-                               void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
-  hipStream_t stream = as_stream(stream_);
+                               void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
+  return gn_layer_run(graph, w, batch, x, x_skip, c_skip, edges, global_in, activation, x_out, edges_out, global_out,
+                      workspace, workspace_bytes, 0, nullptr, as_stream(stream));
+}
+
+int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w,
+                                  int32_t batch, const float* x, const float* global_in, int32_t activation,
+                                  float* x_out, float* global_out, void* workspace, size_t workspace_bytes,
+                                  gunet_stream_t stream) {
+  return gn_upsample_run(graph, n_coarse, w, batch, x, global_in, activation, x_out, global_out, workspace,
+                         workspace_bytes, 0, nullptr, as_stream(stream));
+}
+
+}  // extern "C"
+
+namespace gunet {
+
+int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch, const float* x,
+                 const float* x_skip, int32_t c_skip, const float* const edges[4], const float* global_in,
+                 int32_t activation, float* x_out, float* const edges_out[4], float* global_out, void* workspace,
+                 size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream) {
   LayerWorkspace ws;
   GUNET_TRY(check_layer_args("gn_layer", graph, w, batch, activation, workspace, workspace_bytes, &ws));
-  GUNET_REQUIRE(x && global_in && x_out && global_out && edges && edges_out, "gn_layer: null tensor");
+  GUNET_REQUIRE(x && x_out && edges && edges_out, "gn_layer: null tensor");
+  GUNET_REQUIRE(global_in || (flags & kGnSkipPrologue && flags & kGnSkipGlobalUpdate), "gn_layer: null global_in");
+  GUNET_REQUIRE(global_out || (flags & kGnSkipGlobalUpdate), "gn_layer: null global_out");
   GUNET_REQUIRE(c_skip >= 0 && c_skip % 4 == 0 && c_skip < w->c_in && (c_skip == 0) == (x_skip == nullptr),
                 "gn_layer: bad skip segment (c_skip = %d of c_in = %d)", c_skip, w->c_in);
   GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0 &&
@@ -2095,7 +2192,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
   const int c_a = w->c_in - c_skip;          // width of x; x_skip supplies the remaining columns
   const LayerPtrs p = layer_ptrs(w);
 
-  GUNET_TRY(launch_prologue(p, ut, global_in, relu, 0, batch, ws, stream));
+  if (!(flags & kGnSkipPrologue)) GUNET_TRY(launch_prologue(p, ut, global_in, relu, 0, batch, ws, stream));
 
   {  // node embeddings of the four directions in one GEMM per 128 columns (hybrid_gnn.py:91-92)
     GemmArgs g = {};
@@ -2204,17 +2301,19 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
   g.colsum_tiles = n_partials;
   GUNET_TRY(launch_gemm_columns(g, U, batch, ws.gbias, U, x_out, ws.npart, w_of, ws.wpack, stream));
 
+  if (n_partials_out) *n_partials_out = n_partials;
+  if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
   return launch_global_update(p, ut, global_in, n_partials, relu, batch, ws, global_out, stream);
 }
 
-int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w,
-                                  int32_t batch, const float* x, const float* global_in, int32_t activation,
-                                  float* x_out, float* global_out, void* workspace, size_t workspace_bytes,
-                                  gunet_stream_t stream_) {
-  hipStream_t stream = as_stream(stream_);
+int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w, int32_t batch,
+                    const float* x, const float* global_in, int32_t activation, float* x_out, float* global_out,
+                    void* workspace, size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream) {
   LayerWorkspace ws;
   GUNET_TRY(check_layer_args("gn_upsample", graph, w, batch, activation, workspace, workspace_bytes, &ws));
-  GUNET_REQUIRE(x && global_in && x_out && global_out, "gn_upsample: null tensor");
+  GUNET_REQUIRE(x && x_out, "gn_upsample: null tensor");
+  GUNET_REQUIRE(global_in || (flags & kGnSkipPrologue && flags & kGnSkipGlobalUpdate), "gn_upsample: null global_in");
+  GUNET_REQUIRE(global_out || (flags & kGnSkipGlobalUpdate), "gn_upsample: null global_out");
   GUNET_REQUIRE(n_coarse >= 0 && n_coarse <= graph->n_nodes, "gn_upsample: bad n_coarse");
   const int n_fine = graph->n_nodes - n_coarse;
   int64_t n_edges = 0;
@@ -2230,7 +2329,7 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
 
   // The layer input is [x ; 0]: rows n_coarse.. are zero, so their embedding is act(bias) for every
   // fine node; its product with the receiver rows of the edge kernel is folded into the edge bias.
-  GUNET_TRY(launch_prologue(p, ut, global_in, relu, 1, batch, ws, stream));
+  if (!(flags & kGnSkipPrologue)) GUNET_TRY(launch_prologue(p, ut, global_in, relu, 1, batch, ws, stream));
 
   {  // embeddings of the coarse rows only
     GemmArgs g = {};
@@ -2314,7 +2413,34 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
     }
     GUNET_TRY(launch_gemm_group(blockq, 4, 4, batch, ws.wpack, stream));
   }
+  if (n_partials_out) *n_partials_out = tiles_total;
+  if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
   return launch_global_update(p, ut, global_in, tiles_total, relu, batch, ws, global_out, stream);
 }
 
-}  // extern "C"
+int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int n_partials, const float* global_in,
+              float* global_out, const float* extra, int extra_width, float* cat_out, const gunet_quadgraph* next_graph,
+              const gunet_gn_weights* next, int next_fold_receiver, int32_t batch, int32_t activation, void* workspace,
+              size_t workspace_bytes, hipStream_t stream) {
+  LayerWorkspace wc, wn;
+  GUNET_TRY(check_layer_args("gn_bridge", cur_graph, cur, batch, activation, workspace, workspace_bytes, &wc));
+  GUNET_TRY(check_layer_args("gn_bridge", next_graph, next, batch, activation, workspace, workspace_bytes, &wn));
+  GUNET_REQUIRE(global_in && global_out, "gn_bridge: null global");
+  const int g_new = cur->globt_w ? cur->units : cur->g + cur->units + cur->units / 4;
+  GUNET_REQUIRE(extra ? (extra_width > 0 && cat_out && g_new + extra_width == next->g) : g_new == next->g,
+                "gn_bridge: the next layer takes a global of %d, this one gives %d (+ %d)", next->g, g_new,
+                extra ? extra_width : 0);
+  GUNET_REQUIRE(n_partials >= 0 && n_partials <= wc.n_nblk + 5, "gn_bridge: %d column-sum rows", n_partials);
+  const LayerPtrs pc = layer_ptrs(cur), pn = layer_ptrs(next);
+  const int utc = cur->units / 128, utn = next->units / 128;
+  const size_t lds = sizeof(double) * 4096 + sizeof(float) * (4096 + pc.g + 160 * utc + pn.g + 4 * 32 * utn);
+  GUNET_REQUIRE(lds <= 64 * 1024, "gn_bridge: global vectors of %d and %d floats do not fit", pc.g, pn.g);
+  const int relu = activation == GUNET_ACT_RELU;
+  ProfScope prof(kProfBridge, stream);
+  return utc == 1 ? launch_bridge_utc<1>(pc, pn, utn, lds, batch, global_in, n_partials, wc, relu, global_out, extra,
+                                         extra_width, cat_out, next_fold_receiver, wn, stream)
+                  : launch_bridge_utc<2>(pc, pn, utn, lds, batch, global_in, n_partials, wc, relu, global_out, extra,
+                                         extra_width, cat_out, next_fold_receiver, wn, stream);
+}
+
+}  // namespace gunet

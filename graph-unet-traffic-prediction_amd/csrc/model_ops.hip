@@ -168,15 +168,6 @@ int build_plan(gunet_plan& P, const int64_t* node_loc, int64_t n_nodes, const in
   return GUNET_OK;
 }
 
-// out[b] = [a[b] | c[b]]
-__global__ void k_concat_rows(const float* __restrict__ a, int wa, const float* __restrict__ c, int wc,
-                              float* __restrict__ out) {
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < wa + wc; i += blockDim.x)
-    out[static_cast<int64_t>(b) * (wa + wc) + i] = i < wa ? a[static_cast<int64_t>(b) * wa + i]
-                                                         : c[static_cast<int64_t>(b) * wc + (i - wa)];
-}
-
 // dst[b, 0..row_floats) = src[b, 0..row_floats) for rows that are src_stride / dst_stride floats apart
 __global__ void k_copy_rows(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst,
                             int64_t dst_stride, int64_t row_floats) {
@@ -429,6 +420,23 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
   GUNET_TRY(gunet_dense_forward_f32(x, B * P->levels[0].n_nodes, w->c_in, w->in_kernel, w->in_bias, w->down[0].c_in,
                                     GUNET_ACT_LINEAR, mb.skip_x[0], mb.layer_ws, mb.layer_ws_bytes, stream));
 
+  // Consecutive GN layers are joined: the global update that ends one layer and the prologue that
+  // starts the next (both one small workgroup per sample) run as one kernel, gn_bridge.  `pend` is
+  // the layer whose global update is still owed.
+  struct {
+    const gunet_quadgraph* graph;
+    const gunet_gn_weights* w;
+    int n_partials;
+    const float* g_in;
+    float* g_out;
+  } pend = {};
+  const int mid = kGnSkipPrologue | kGnSkipGlobalUpdate;
+  auto enter = [&](const gunet_quadgraph* graph, const gunet_gn_weights* gw, int fold_receiver, const float* extra,
+                   int extra_width, float* cat_out) {
+    return gn_bridge(pend.graph, pend.w, pend.n_partials, pend.g_in, pend.g_out, extra, extra_width, cat_out, graph, gw,
+                     fold_receiver, batch, activation, mb.layer_ws, mb.layer_ws_bytes, stream);
+  };
+
   // down path (:67-71): GN layer, then 2x2 pooling; what enters each block stays for the way up
   const float* cur_g = global_in;
   for (int l = 0; l < D; ++l) {
@@ -437,9 +445,11 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
     const gunet_plan::Pool& pool = P->pools[l];
     const gunet_gn_weights& gw = w->down[l];
     const float* const* e_in = l == 0 ? edges : mb.skip_e[l].q;
-    GUNET_TRY(gunet_gn_layer_forward_f32(&L.qg, &gw, batch, mb.skip_x[l], nullptr, 0, e_in, cur_g, activation,
-                                         mb.tmp_x[0], mb.tmp_e[0].q, mb.skip_g[l + 1], mb.layer_ws, mb.layer_ws_bytes,
-                                         stream));
+    if (l > 0) GUNET_TRY(enter(&L.qg, &gw, 0, nullptr, 0, nullptr));
+    pend = {&L.qg, &gw, 0, cur_g, mb.skip_g[l + 1]};
+    GUNET_TRY(gn_layer_run(&L.qg, &gw, batch, mb.skip_x[l], nullptr, 0, e_in, cur_g, activation, mb.tmp_x[0],
+                           mb.tmp_e[0].q, nullptr, mb.layer_ws, mb.layer_ws_bytes, l == 0 ? kGnSkipGlobalUpdate : mid,
+                           &pend.n_partials, stream));
     cur_g = mb.skip_g[l + 1];
     {  // graph_pooling_2x2 (hybrid_gnn.py:427, :401): node features and the four edge-feature sets
       const float* src[5] = {mb.tmp_x[0]};
@@ -466,10 +476,13 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
   const float* const* cur_e = mb.skip_e[D].q;
   int side = 0;   // tmp buffer the next layer writes
   for (int i = 0; i < 2; ++i) {
+    const gunet_quadgraph* graph = &P->levels[D].qg;
     float* g_out = next_global();
-    GUNET_TRY(gunet_gn_layer_forward_f32(&P->levels[D].qg, &w->bottleneck[i], batch, cur_x, nullptr, 0, cur_e, cur_g,
-                                         activation, mb.tmp_x[side], mb.tmp_e[side].q, g_out, mb.layer_ws,
-                                         mb.layer_ws_bytes, stream));
+    GUNET_TRY(enter(graph, &w->bottleneck[i], 0, nullptr, 0, nullptr));
+    pend = {graph, &w->bottleneck[i], 0, cur_g, g_out};
+    GUNET_TRY(gn_layer_run(graph, &w->bottleneck[i], batch, cur_x, nullptr, 0, cur_e, cur_g, activation,
+                           mb.tmp_x[side], mb.tmp_e[side].q, nullptr, mb.layer_ws, mb.layer_ws_bytes, mid,
+                           &pend.n_partials, stream));
     cur_x = mb.tmp_x[side];
     cur_e = mb.tmp_e[side].q;
     cur_g = g_out;
@@ -483,22 +496,22 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
     const gunet_plan::Level& C = P->levels[l + 1];
     const gunet_gn_weights& up = w->up_sampling[i];
     const float* target_g = l == 0 ? global_in : mb.skip_g[l];
-    const int wa = up.g - (l == 0 ? w->down[0].g : global_out_width(w->down[l - 1]));
-    float* g_cat = next_global();
-    k_concat_rows<<<batch, 256, 0, stream>>>(cur_g, wa, target_g, up.g - wa, g_cat);   // hybrid_gnn.py:375
-    GUNET_LAUNCH_CHECK();
+    const int target_width = l == 0 ? w->down[0].g : global_out_width(w->down[l - 1]);
+    float* g_cat = next_global();   // [global | target global], hybrid_gnn.py:375
     float* g_up = next_global();
-    if (P->one_parent_edge[l]) {
-      GUNET_TRY(gunet_gn_upsample_forward_f32(&P->ups[l].qg, static_cast<int32_t>(C.n_nodes), &up, batch, cur_x, g_cat,
-                                              activation, mb.tmp_x[side], g_up, mb.layer_ws, mb.layer_ws_bytes,
-                                              stream));
+    const bool fast = P->one_parent_edge[l];
+    GUNET_TRY(enter(&P->ups[l].qg, &up, fast ? 1 : 0, target_g, target_width, g_cat));
+    pend = {&P->ups[l].qg, &up, 0, g_cat, g_up};
+    if (fast) {
+      GUNET_TRY(gn_upsample_run(&P->ups[l].qg, static_cast<int32_t>(C.n_nodes), &up, batch, cur_x, g_cat, activation,
+                                mb.tmp_x[side], nullptr, mb.layer_ws, mb.layer_ws_bytes, mid, &pend.n_partials, stream));
     } else {   // hybrid_gnn.py:342-344, 373-377 as written: the layer on [x ; zeros] with zero edge features
       const int64_t n_all = C.n_nodes + L.n_nodes;
       GUNET_HIP_TRY(hipMemsetAsync(mb.up_in, 0, sizeof(float) * B * n_all * up.c_in, stream));
       GUNET_TRY(copy_rows(cur_x, C.n_nodes * up.c_in, mb.up_in, n_all * up.c_in, C.n_nodes * up.c_in, B, stream));
       const float* no_edges[4] = {};
-      GUNET_TRY(gunet_gn_layer_forward_f32(&P->ups[l].qg, &up, batch, mb.up_in, nullptr, 0, no_edges, g_cat, activation,
-                                           mb.up_out, mb.tmp_e[side].q, g_up, mb.layer_ws, mb.layer_ws_bytes, stream));
+      GUNET_TRY(gn_layer_run(&P->ups[l].qg, &up, batch, mb.up_in, nullptr, 0, no_edges, g_cat, activation, mb.up_out,
+                             mb.tmp_e[side].q, nullptr, mb.layer_ws, mb.layer_ws_bytes, mid, &pend.n_partials, stream));
       GUNET_TRY(copy_rows(mb.up_out + C.n_nodes * up.units, n_all * up.units, mb.tmp_x[side], L.n_nodes * up.units,
                           L.n_nodes * up.units, B, stream));
     }
@@ -517,9 +530,12 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
         e_out = last_e;
       }
       const int c_skip = j == 0 ? gw.c_in - up.units : 0;   // concat(x, x_skip), hybrid_gnn.py:235
-      GUNET_TRY(gunet_gn_layer_forward_f32(&L.qg, &gw, batch, cur_x, j == 0 ? mb.skip_x[l] : nullptr, c_skip, e_in,
-                                           cur_g, activation, mb.tmp_x[side], e_out, g_out, mb.layer_ws,
-                                           mb.layer_ws_bytes, stream));
+      GUNET_TRY(enter(&L.qg, &gw, 0, nullptr, 0, nullptr));
+      pend = {&L.qg, &gw, 0, cur_g, g_out};
+      // the last layer of the model finishes its own global
+      GUNET_TRY(gn_layer_run(&L.qg, &gw, batch, cur_x, j == 0 ? mb.skip_x[l] : nullptr, c_skip, e_in, cur_g, activation,
+                             mb.tmp_x[side], e_out, last ? g_out : nullptr, mb.layer_ws, mb.layer_ws_bytes,
+                             last ? kGnSkipPrologue : mid, &pend.n_partials, stream));
       cur_x = mb.tmp_x[side];
       e_in = e_out == last_e ? nullptr : mb.tmp_e[side].q;
       cur_g = g_out;

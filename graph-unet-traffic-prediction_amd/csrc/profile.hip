@@ -23,7 +23,7 @@ std::vector<hipEvent_t> g_free_events; // reusable events
 const char* const kNames[kProfCount] = {"gemm_tiled",    "edge_mlp",       "aggregate",   "layer_prologue",
                                         "global_update", "segment_reduce", "gather_rows", "dense_naive",
                                         "gemm_resident_k128", "gemm_resident_k256", "gemm_split",
-                                        "gemm_resident_k384", "gemm_resident_bf16"};
+                                        "gemm_resident_k384", "gemm_resident_bf16", "global_bridge"};
 
 hipEvent_t take_event() {
   if (!g_free_events.empty()) {

@@ -377,8 +377,9 @@ int gunet_error_sums_f32(const float* y_true, const float* y_pred, int64_t n_row
  * 4 global_update, 5 segment_reduce, 6 gather_rows, 7 dense_naive, 8 gemm_resident_k128
  * (k_gemm_resident<*, 4>), 9 gemm_resident_k256 (k_gemm_resident<*, 8>), 10 gemm_split
  * (k_pack_weights + k_gemm_split), 11 gemm_resident_k384 (k_gemm_resident<2, 12>),
- * 12 gemm_resident_bf16 (k_gemm_resident<.., BF16 = true>). */
-#define GUNET_PROF_CLASSES 13
+ * 12 gemm_resident_bf16 (k_gemm_resident<.., BF16 = true>), 13 global_bridge (k_global_bridge: one
+ * layer's global update joined with the next layer's prologue, whole-model entry point only). */
+#define GUNET_PROF_CLASSES 14
 int gunet_profile_enable(int on);
 int gunet_profile_collect(double ms_host[GUNET_PROF_CLASSES], int64_t launches_host[GUNET_PROF_CLASSES],
                           double work_host[GUNET_PROF_CLASSES]);
