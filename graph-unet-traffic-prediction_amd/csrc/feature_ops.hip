@@ -413,10 +413,14 @@ constexpr size_t kResMaxLds = 160 * 1024;
 // accumulate and storage); a lane then owns, per 16-wide k step, 8 consecutive floats of its row
 // (k = 16s + 8 * lh + 0..7), and the LDS weight image holds one bf16x8 per lane, k step and column
 // tile.  The matrix work shrinks 16-fold, so this form runs at the speed of its memory traffic.
-template <int NT, int NKT, bool GATHER, bool BF16>
+// RAGGED = true (one operand segment, float32): k is not a whole number of K tiles; the weight rows
+// past k are zero in the LDS image and the last tile's loads past k are redirected to the row's
+// first piece of that tile and zeroed.
+template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
 __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(
     GemmArgs g, int groups_per_sample, int wps, int gpw, int batch) {
   static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
+  static_assert(!RAGGED || (!GATHER && !BF16), "the ragged form is float32 without gathering");
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   constexpr int NX = GATHER ? NKT - 4 : NKT;   // K tiles read from the operand segments
   constexpr int BN = 32 * NT;
@@ -448,9 +452,12 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
             img[((k0 >> 4) * NT + t) * 64 + ((k0 >> 3) & 1) * 32 + col] = __builtin_bit_cast(uint4, v);
           }
         } else {
-          for (int i = tid; i < sg.k * 8; i += kWaves * 64) {
+          const int k_fill = RAGGED ? kBK * NKT : sg.k;
+          for (int i = tid; i < k_fill * 8; i += kWaves * 64) {
             const int row = kbase + (i >> 3), c4 = i & 7;
-            const float4 v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!RAGGED || (i >> 3) < sg.k)
+              v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
             // row = 8 * chunk + 4 * half + j
             float* dst = Ws + (((row >> 3) * NT + t) * 64 + ((row >> 2) & 1) * 32 + 4 * c4) * 4 + (row & 3);
             dst[0] = v.x;
@@ -485,12 +492,23 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // uniform base pointer + 32-bit per-lane byte offset (the host checks that every operand
   // segment and the output are smaller than 4 GiB)
   auto load_tile = [&](uint32_t arow, int kt, float4 (&a)[4]) {
-    const int s = kt < t0 ? 0 : (kt < t0 + t1 ? 1 : 2);
+    const int s = RAGGED ? 0 : (kt < t0 ? 0 : (kt < t0 + t1 ? 1 : 2));
     const int k0 = kBK * (kt - (s == 0 ? 0 : (s == 1 ? t0 : t0 + t1)));
     const float* base = s == 0 ? g.seg[0].a : (s == 1 ? g.seg[1].a : g.seg[2].a);
     const uint32_t lda = static_cast<uint32_t>(s == 0 ? g.seg[0].lda : (s == 1 ? g.seg[1].lda : g.seg[2].lda));
     const char* sb = reinterpret_cast<const char*>(base + k0);
     const uint32_t voff = (arow * lda + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
+    if (RAGGED && kt == NKT - 1) {
+      const int left = g.seg[0].k - kBK * (NKT - 1) - 4 * lh;   // floats of this lane's k phase left in the tile
+      const uint32_t first = static_cast<uint32_t>(arow * lda) * 4u;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = 8 * c < left;
+        const float4 v = *reinterpret_cast<const float4*>(sb + (ok ? voff + chunk_bytes(c) : first));
+        a[c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const float4*>(sb + voff + chunk_bytes(c));
   };
@@ -515,6 +533,8 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        // ragged form: 8-float pieces of the last tile that lie wholly past k are zero -- skip them
+        if (RAGGED && kt == NKT - 1 && 8 * c >= g.seg[0].k - kBK * (NKT - 1)) continue;
         float4 w[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) w[n] = wl[((kt * 4 + c) * NT + n) * 64];
@@ -992,12 +1012,18 @@ inline size_t resident_lds_bytes(int nt, int nkt, bool bf16) {
   return (bf16 ? 2 : 4) * static_cast<size_t>(32 * nkt) * 32 * nt + sizeof(float) * kResWaves * 16 * 32;
 }
 
+inline bool resident_ragged(const GemmArgs& g) {
+  return g.n_seg == 1 && g.gather_table == nullptr && g.seg[0].k % kBK != 0 && g.seg[0].k % 4 == 0 &&
+         g.seg[0].k > 3 * kBK && g.seg[0].k < 4 * kBK;
+}
+
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   if (g.row_map != nullptr) return false;
   if (mode_pieces(g_matmul_mode) > 1) return false;   // split-bf16 modes: tiled kernel only
   const bool bf16 = bf16_mode();
+  const bool ragged = resident_ragged(g);   // one float32 segment of 97..127 columns, 128 output columns
   for (int s = 0; s < g.n_seg; ++s)
-    if (g.seg[s].k % kBK != 0) return false;
+    if (g.seg[s].k % kBK != 0 && !(ragged && !bf16 && nt == 4)) return false;
   const int kt = gemm_ktiles(g);
   if (bf16) {   // 96 or 128 columns, 4 / 8 / 12 K tiles; gathering form: 128 columns, 8 or 12 K tiles
     if (g.gather_table != nullptr ? !(nt == 4 && (kt == 8 || kt == 12)) : !((nt == 3 || nt == 4) && (kt == 4 || kt == 8)))
@@ -1064,7 +1090,7 @@ inline int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void
   return static_cast<int>(ceil_div(g.n_rows, kBM));
 }
 
-template <int NT, int NKT, bool GATHER, bool BF16>
+template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
 int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   static bool raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
   const size_t lds = resident_lds_bytes(NT, NKT, BF16);
@@ -1072,15 +1098,15 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   GUNET_HIP_TRY(hipGetDevice(&dev));
   GUNET_REQUIRE(dev >= 0 && dev < 64, "launch_gemm: device index %d", dev);
   if (!raised[dev]) {
-    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER, BF16>),
+    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResMaxLds)));
     raised[dev] = true;
   }
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
   const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kWaves));
-  k_gemm_resident<NT, NKT, GATHER, BF16><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw,
-                                                                             static_cast<int>(batch));
+  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw,
+                                                                                     static_cast<int>(batch));
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
@@ -1100,6 +1126,7 @@ int launch_gemm_resident(const GemmArgs& g, int nt, int64_t batch, hipStream_t s
   if (g.gather_table != nullptr)
     return nt == 4 ? launch_resident_inst<4, 8, true, false>(g, batch, stream)
                    : launch_resident_inst<2, 12, true, false>(g, batch, stream);
+  if (resident_ragged(g)) return launch_resident_inst<4, 4, false, false, true>(g, batch, stream);
   if (nt == 4)
     return kt == 4 ? launch_resident_inst<4, 4, false, false>(g, batch, stream)
                    : launch_resident_inst<4, 8, false, false>(g, batch, stream);
@@ -1660,7 +1687,15 @@ __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const flo
     const int q = col / u, c = col % u;
     double s = 0.0;
     const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(u) + c;
-    for (int i = grp; i < n_eblk; i += EG) s += static_cast<double>(src[static_cast<int64_t>(i) * u]);
+    int i = grp;
+    for (; i + 7 * EG < n_eblk; i += 8 * EG) {   // eight partial rows in flight, added in order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[static_cast<int64_t>(i + j * EG) * u];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += static_cast<double>(v[j]);
+    }
+    for (; i < n_eblk; i += EG) s += static_cast<double>(src[static_cast<int64_t>(i) * u]);
     dpart[grp * U + col] = s;
   }
   __syncthreads();

@@ -369,6 +369,31 @@ def test_graph_unet_kernel_choices(amd, oracle, choice):
     assert rel_err(got_glob, want_g['global']) <= TOL
 
 
+@pytest.mark.parametrize('k', [104, 100, 124, 116])
+def test_dense_ragged_k_resident(amd, resident_kernels, k):
+    """Input widths that are not a whole number of 32-wide K tiles (the model's 104-column in_layer) on
+    the weights-resident GEMM: the last tile's missing columns are masked, rows are not a multiple of
+    the 32-row groups, and NaNs planted behind the last row's end must not leak in through the
+    redirected loads.  Same result as the tiled kernel to rounding, and as float64 to 1e-5."""
+    rng = np.random.Generator(np.random.PCG64(40 + k))
+    rows, n = 1000 + k, 128
+    buf = torch.full((rows * k + 64,), float('nan'), device='cuda')
+    x = rng.standard_normal((rows, k)).astype(np.float32)
+    buf[:rows * k] = to_dev(x).reshape(-1)
+    xd = buf[:rows * k].view(rows, k)
+    w = rng.standard_normal((k, n)).astype(np.float32) * 0.1
+    b = rng.standard_normal(n).astype(np.float32)
+    layer = amd.hybrid_gnn.Dense(n, activation='relu', use_bias=True)
+    layer.load_weights({'d/kernel': w, 'd/bias': b}, 'd', 'cuda')
+    got = layer(xd).cpu().numpy()
+    want = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0)
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) <= TOL
+    amd.set_kernel_choice('tiled')
+    tiled = layer(xd).cpu().numpy()
+    assert rel_err(got, tiled) <= 1e-6
+
+
 def test_gn_layer_fused_aggregation_edge_cases(amd, oracle, resident_kernels):
     """The message-summing node MLP on a grid graph with one quadrant emptied and a skip segment
     (three operand segments), single sample and batched."""
