@@ -57,10 +57,27 @@ __global__ void k_segment_reduce(const float* __restrict__ src, int64_t n_src, i
   const int c = static_cast<int>(idx % wv) * V;
   const int64_t b = blockIdx.y;
   const float* s = src + b * n_src * width + c;
-  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  const int beg = rowptr[seg];
+  int end = rowptr[seg + 1];
   float acc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = IS_MAX ? -FLT_MAX : 0.0f;
+  if (IS_MAX && V == 4) {   // four member rows in flight (a repeated member does not change a maximum)
+    for (int p = beg; p < end; p += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i] = *reinterpret_cast<const float4*>(s + static_cast<int64_t>(perm[p + i < end ? p + i : beg]) * width);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0] = fmaxf(acc[0], v[i].x);
+        acc[1] = fmaxf(acc[1], v[i].y);
+        acc[2] = fmaxf(acc[2], v[i].z);
+        acc[3] = fmaxf(acc[3], v[i].w);
+      }
+    }
+    end = beg;   // nothing left for the generic walk below
+  }
   for (int p = beg; p < end; ++p) {
     const float* row = s + static_cast<int64_t>(perm[p]) * width;
     if (V == 4) {
@@ -144,12 +161,20 @@ __global__ void k_pool_max(PoolJobs j) {
   const int32_t* perm = j.perm[job];
   const int beg = rowptr[seg], end = rowptr[seg + 1];
   float4 acc = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-  for (int p = beg; p < end; ++p) {
-    const float4 v = *reinterpret_cast<const float4*>(s + static_cast<int64_t>(perm[p]) * width);
-    acc.x = fmaxf(acc.x, v.x);
-    acc.y = fmaxf(acc.y, v.y);
-    acc.z = fmaxf(acc.z, v.z);
-    acc.w = fmaxf(acc.w, v.w);
+  for (int p = beg; p < end; p += 4) {   // a 2x2 cell has at most four members: all rows in flight at once
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pi = p + i < end ? p + i : beg;   // a repeated member does not change a maximum
+      v[i] = *reinterpret_cast<const float4*>(s + static_cast<int64_t>(perm[pi]) * width);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc.x = fmaxf(acc.x, v[i].x);
+      acc.y = fmaxf(acc.y, v[i].y);
+      acc.z = fmaxf(acc.z, v[i].z);
+      acc.w = fmaxf(acc.w, v[i].w);
+    }
   }
   *reinterpret_cast<float4*>(j.out[job] + (b * n_seg + seg) * width + c) = acc;
 }
@@ -1247,11 +1272,11 @@ constexpr int kSmallThreads = 1024;   // the two per-sample kernels
 // row-major with U columns, S = 1024 / (U/4) row subsets; the caller adds the S subsets in
 // order.  Four rows are in flight per thread.
 template <int U>
-__device__ inline float4 matvec_partial(const float* v, const float* w, int n_rows, int sub, int cq) {
+__device__ inline float4 matvec_partial(const float* v, const float* w, int n_rows, int sub, int cq, int first = 0,
+                                        float4 s = make_float4(0.f, 0.f, 0.f, 0.f)) {
   constexpr int QC = U / 4, S = kSmallThreads / QC;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* w4 = reinterpret_cast<const float4*>(w) + cq;
-  int r = sub;
+  int r = sub + first * S;   // `s` already holds this thread's rows sub, sub + S, ... below r
   for (; r + 3 * S < n_rows; r += 4 * S) {
     const float4 a0 = w4[static_cast<int64_t>(r) * QC];
     const float4 a1 = w4[static_cast<int64_t>(r + S) * QC];
@@ -1274,6 +1299,38 @@ __device__ inline float4 matvec_partial(const float* v, const float* w, int n_ro
   return s;
 }
 
+// The first NPRE of a thread's rows of that product, fetched ahead of the vector: matvec_head_load
+// when the weights are known, matvec_head_apply (the same fused multiply-adds in the same order as
+// matvec_partial would do) once the vector is there; matvec_partial(.., first = NPRE, s) finishes.
+template <int U, int NPRE>
+__device__ inline void matvec_head_load(const float* w, int n_rows, int sub, int cq, float4 (&pre)[NPRE]) {
+  constexpr int QC = U / 4, S = kSmallThreads / QC;
+  const float4* w4 = reinterpret_cast<const float4*>(w) + cq;
+#pragma unroll
+  for (int j = 0; j < NPRE; ++j) {
+    const int r = sub + j * S;
+    pre[j] = r < n_rows ? w4[static_cast<int64_t>(r) * QC] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int U, int NPRE>
+__device__ inline float4 matvec_head_apply(const float* v, int n_rows, int sub, const float4 (&pre)[NPRE]) {
+  constexpr int S = kSmallThreads / (U / 4);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NPRE; ++j) {
+    const int r = sub + j * S;
+    if (r < n_rows) {
+      const float x = v[r];
+      s.x = fmaf(x, pre[j].x, s.x);
+      s.y = fmaf(x, pre[j].y, s.y);
+      s.z = fmaf(x, pre[j].z, s.z);
+      s.w = fmaf(x, pre[j].w, s.w);
+    }
+  }
+  return s;
+}
+
 // Adds `n` partials of column `col` (row stride `ld`) in order.
 __device__ inline float combine_rows(const float* part, int n, int ld, int col) {
   float s = part[col];
@@ -1286,50 +1343,87 @@ __device__ inline float combine_rows(const float* part, int n, int ld, int col) 
 // and the four node-embedding biases laid side by side.  Everything that does not depend on the
 // chain (the node-MLP bias, the constant receiver term of the upsampling form, and the weights the
 // later chain steps need) is fetched first, so the chain itself only waits on LDS.
-// `gl` (LDS, [g]) holds the sample's global vector; it may still be in the making when the body
-// starts (the first barrier below covers it).  `part` is 4096 floats of LDS scratch, `gq` [4][u].
-template <int UT>
-__device__ __forceinline__ void prologue_body(const LayerPtrs& p, const float* gl, int relu, int fold_receiver,
-                                              int64_t b, float* part, float* gq, float* __restrict__ nbias,
-                                              float* __restrict__ ebias, float* __restrict__ gbias) {
-  constexpr int U = 128 * UT, u = 32 * UT;
-  constexpr int QC = U / 4, S = kSmallThreads / QC;     // matvec: column quads x row subsets
-  constexpr int CG = kSmallThreads / u, CR = u / CG;    // chain: CG row groups, CR rows each (u -> u steps)
-  constexpr int EG = kSmallThreads / U, ER = u / EG;    // edge bias: EG row groups, ER rows each
-  const int tid = threadIdx.x;
+// Split in two so that a caller with other work to do first (k_global_bridge) can have the weight
+// loads in flight behind it: prologue_prefetch fetches what does not depend on the global vector
+// (DEEP: also the first rows of the two products that start from it), prologue_compute does the rest.
+constexpr int kPreNode = 4;    // rows of the node-MLP bias product fetched ahead, per thread
+constexpr int kPreChain = 4;   // rows of the first chain step fetched ahead, per thread
 
-  const int cgrp = tid / u, ccol = tid % u;
+template <int UT>
+struct ProloguePre {
+  static constexpr int u = 32 * UT, U = 128 * UT;
+  static constexpr int CG = kSmallThreads / u, CR = u / CG;   // chain: CG row groups, CR rows each (u -> u steps)
+  static constexpr int EG = kSmallThreads / U, ER = u / EG;   // edge bias: EG row groups, ER rows each
   float wq[3][CR];
+  float we[ER];
+  float e_const;
+  float4 node_w[kPreNode];
+  float chain_w[kPreChain];
+};
+
+template <int UT, bool DEEP>
+__device__ __forceinline__ void prologue_prefetch(const LayerPtrs& p, int relu, int fold_receiver, int64_t b,
+                                                  float* __restrict__ nbias, ProloguePre<UT>& pre) {
+  constexpr int U = 128 * UT, u = 32 * UT;
+  constexpr int QC = U / 4;
+  constexpr int CG = ProloguePre<UT>::CG, CR = ProloguePre<UT>::CR, EG = ProloguePre<UT>::EG, ER = ProloguePre<UT>::ER;
+  const int tid = threadIdx.x;
+  const int cgrp = tid / u, ccol = tid % u;
 #pragma unroll
   for (int q = 1; q < 4; ++q)
 #pragma unroll
-    for (int i = 0; i < CR; ++i) wq[q - 1][i] = p.glob_w[q][(cgrp + CG * i) * u + ccol];
+    for (int i = 0; i < CR; ++i) pre.wq[q - 1][i] = p.glob_w[q][(cgrp + CG * i) * u + ccol];
   const int egrp = tid / U, ecol = tid % U;
   const int eq = ecol / u, ej = ecol % u;
-  float we[ER];
   {
     const float* w = p.edge_w[eq] + static_cast<int64_t>(p.f_e + 2 * u) * u;
 #pragma unroll
-    for (int i = 0; i < ER; ++i) we[i] = w[(egrp + EG * i) * u + ej];
+    for (int i = 0; i < ER; ++i) pre.we[i] = w[(egrp + EG * i) * u + ej];
   }
-  float e_const = 0.0f;
+  if (DEEP) {
+    matvec_head_load<U, kPreNode>(p.node_w + static_cast<int64_t>(p.c_in + U) * U, p.g, tid / QC, tid % QC, pre.node_w);
+#pragma unroll
+    for (int i = 0; i < kPreChain; ++i) {
+      const int k = cgrp + CG * i;
+      pre.chain_w[i] = k < p.g ? p.glob_w[0][k * u + ccol] : 0.0f;
+    }
+  }
+  pre.e_const = 0.0f;
   if (tid < U) {
-    if (p.edge_b[eq]) e_const = p.edge_b[eq][ej];
+    if (p.edge_b[eq]) pre.e_const = p.edge_b[eq][ej];
     if (fold_receiver) {
       // every receiver is a zero input row: its embedding is act(bias), a constant of the layer
       const float* wr = p.edge_w[eq] + static_cast<int64_t>(p.f_e + u) * u;
       float r = 0.0f;
       for (int k = 0; k < u; ++k)
         r = fmaf(activate(p.node_emb_b[eq] ? p.node_emb_b[eq][k] : 0.0f, relu), wr[k * u + ej], r);
-      e_const += r;
+      pre.e_const += r;
     }
     if (b == 0) nbias[tid] = p.node_emb_b[eq] ? p.node_emb_b[eq][ej] : 0.0f;
   }
+}
+
+// `gl` (LDS, [g]) holds the sample's global vector; it may still be in the making when this starts
+// (the first barrier below covers it).  `part` is 4096 floats of LDS scratch, `gq` [4][u].
+template <int UT, bool DEEP>
+__device__ __forceinline__ void prologue_compute(const LayerPtrs& p, const float* gl, int relu, int64_t b, float* part,
+                                                 float* gq, float* __restrict__ ebias, float* __restrict__ gbias,
+                                                 const ProloguePre<UT>& pre) {
+  constexpr int U = 128 * UT, u = 32 * UT;
+  constexpr int QC = U / 4, S = kSmallThreads / QC;     // matvec: column quads x row subsets
+  constexpr int CG = ProloguePre<UT>::CG, CR = ProloguePre<UT>::CR, EG = ProloguePre<UT>::EG, ER = ProloguePre<UT>::ER;
+  const int tid = threadIdx.x;
+  const int cgrp = tid / u, ccol = tid % u;
+  const int egrp = tid / U, ecol = tid % U;
+  const int eq = ecol / u;
   __syncthreads();
 
   {  // node-MLP bias: global . W[c_in + U .., :]
     const int sub = tid / QC, cq = tid % QC;
-    const float4 s = matvec_partial<U>(gl, p.node_w + static_cast<int64_t>(p.c_in + U) * U, p.g, sub, cq);
+    const float* w = p.node_w + static_cast<int64_t>(p.c_in + U) * U;
+    const float4 s = DEEP ? matvec_partial<U>(gl, w, p.g, sub, cq, kPreNode,
+                                              matvec_head_apply<U, kPreNode>(gl, p.g, sub, pre.node_w))
+                          : matvec_partial<U>(gl, w, p.g, sub, cq);
     *reinterpret_cast<float4*>(&part[sub * U + 4 * cq]) = s;
   }
   __syncthreads();
@@ -1342,7 +1436,13 @@ __device__ __forceinline__ void prologue_body(const LayerPtrs& p, const float* g
 
   {  // chain step 0: [g] -> u
     float s = 0.0f;
-    for (int k = cgrp; k < p.g; k += CG) s = fmaf(gl[k], p.glob_w[0][k * u + ccol], s);
+    int k = cgrp;
+    if (DEEP) {
+#pragma unroll
+      for (int i = 0; i < kPreChain; ++i, k += CG)
+        if (k < p.g) s = fmaf(gl[k], pre.chain_w[i], s);
+    }
+    for (; k < p.g; k += CG) s = fmaf(gl[k], p.glob_w[0][k * u + ccol], s);
     part[cgrp * u + ccol] = s;
   }
   __syncthreads();
@@ -1357,7 +1457,7 @@ __device__ __forceinline__ void prologue_body(const LayerPtrs& p, const float* g
       const float* src = gq + (q - 1) * u;
       float s = 0.0f;
 #pragma unroll
-      for (int i = 0; i < CR; ++i) s = fmaf(src[cgrp + CG * i], wq[q - 1][i], s);
+      for (int i = 0; i < CR; ++i) s = fmaf(src[cgrp + CG * i], pre.wq[q - 1][i], s);
       part[cgrp * u + ccol] = s;
     }
     __syncthreads();
@@ -1371,11 +1471,11 @@ __device__ __forceinline__ void prologue_body(const LayerPtrs& p, const float* g
   {  // edge bias of direction eq: chained global of that direction . W_global + constants
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < ER; ++i) s = fmaf(gq[eq * u + egrp + EG * i], we[i], s);
+    for (int i = 0; i < ER; ++i) s = fmaf(gq[eq * u + egrp + EG * i], pre.we[i], s);
     part[egrp * U + ecol] = s;
   }
   __syncthreads();
-  if (tid < U) ebias[b * U + tid] = combine_rows(part, EG, U, tid) + e_const;
+  if (tid < U) ebias[b * U + tid] = combine_rows(part, EG, U, tid) + pre.e_const;
 }
 
 template <int UT>
@@ -1391,7 +1491,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
   float* gq = gl + p.g;                  // [4][u]
   const int64_t b = blockIdx.x;
   for (int k = threadIdx.x; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
-  prologue_body<UT>(p, gl, relu, fold_receiver, b, part, gq, nbias, ebias, gbias);
+  ProloguePre<UT> pre;
+  prologue_prefetch<UT, false>(p, relu, fold_receiver, b, nbias, pre);
+  prologue_compute<UT, false>(p, gl, relu, b, part, gq, ebias, gbias, pre);
 }
 
 struct EdgeArgs {
@@ -1634,11 +1736,14 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
 // LDS: dpart 4096 doubles, part 4096 floats, gin [g + U + u] whose first g entries the caller
 // fills with the layer's input global (the first barrier below covers that).  The new global goes
 // to global_out and, when `keep` is not null, also to keep[0 .. width of the new global) in LDS.
+constexpr int kPreGlobT = 8;   // rows of the glob_transform product fetched ahead, per thread (head != nullptr)
+
 template <int UT>
 __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const float* __restrict__ npart, int n_nblk,
                                                    const float* __restrict__ epart, int n_eblk, int relu, int64_t b,
                                                    double* dpart, float* part, float* gin,
-                                                   float* __restrict__ global_out, float* keep) {
+                                                   float* __restrict__ global_out, float* keep,
+                                                   const float4 (*head)[kPreGlobT] = nullptr) {
   constexpr int U = 128 * UT, u = 32 * UT;
   constexpr int QC = U / 4, S = kSmallThreads / QC;
   constexpr int EG = kSmallThreads / U;
@@ -1712,7 +1817,9 @@ __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const flo
   __syncthreads();
   const int kin = p.g + U + u;
   if (p.globt_w != nullptr) {
-    const float4 s = matvec_partial<U>(gin, p.globt_w, kin, sub, cq);
+    const float4 s = head ? matvec_partial<U>(gin, p.globt_w, kin, sub, cq, kPreGlobT,
+                                              matvec_head_apply<U, kPreGlobT>(gin, kin, sub, *head))
+                          : matvec_partial<U>(gin, p.globt_w, kin, sub, cq);
     *reinterpret_cast<float4*>(&part[sub * U + 4 * cq]) = s;
     __syncthreads();
     if (tid < U) {
@@ -1767,15 +1874,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
   float* gq = gl + pn.g;                                   // [4][u] of the next layer
   const int64_t b = blockIdx.x;
   for (int k = threadIdx.x; k < pc.g; k += blockDim.x) gin[k] = global_in[b * pc.g + k];
-  global_update_body<UTC>(pc, npart, n_nblk, epart, n_eblk, relu, b, dpart, part, gin, global_out, gl);
+  // every weight the two stages will want first is requested now, behind the column sums
+  ProloguePre<UTN> pre;
+  prologue_prefetch<UTN, true>(pn, relu, fold_receiver, b, nbias, pre);
+  float4 head[kPreGlobT];
+  if (pc.globt_w != nullptr)
+    matvec_head_load<128 * UTC, kPreGlobT>(pc.globt_w, pc.g + 160 * UTC, threadIdx.x / (32 * UTC),
+                                           threadIdx.x % (32 * UTC), head);
+  global_update_body<UTC>(pc, npart, n_nblk, epart, n_eblk, relu, b, dpart, part, gin, global_out, gl,
+                          pc.globt_w != nullptr ? &head : nullptr);
   if (extra != nullptr) {
     const int w0 = pn.g - extra_width;   // width of the new global
     for (int k = threadIdx.x; k < extra_width; k += blockDim.x) gl[w0 + k] = extra[b * extra_width + k];
     __syncthreads();
     for (int k = threadIdx.x; k < pn.g; k += blockDim.x) cat_out[b * pn.g + k] = gl[k];
   }
-  __syncthreads();   // `part` is free again and gl complete
-  prologue_body<UTN>(pn, gl, relu, fold_receiver, b, part, gq, nbias, ebias, gbias);
+  // the barrier that opens prologue_compute frees `part` and completes gl
+  prologue_compute<UTN, true>(pn, gl, relu, b, part, gq, ebias, gbias, pre);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -129,6 +129,22 @@ def test_unet_forward_one_call(amd, oracle, size, batch):
     assert rel_err(y1.cpu().numpy(), oracle.graph_unet_forward(xs[0], copy_graph(graphs[0]), W)[0]) <= TOL
 
 
+@pytest.mark.parametrize('size', [(2, 2), (3, 5), (1, 7), (5, 4)])
+def test_unet_forward_tiny_graphs(amd, oracle, size):
+    """Graphs that run out of edges (and nearly of nodes) on the way down: the deeper levels have a
+    single node or no edges at all in some or all quadrants."""
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    x, graph, _ = make_case(oracle, size[0], size[1], 1.0, dense=True)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    got_y, got_g = model(to_dev(x), graph_to_dev(graph))
+    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    model.native_forward = False
+    ref_y, ref_g = model(to_dev(x), graph_to_dev(graph))
+    assert torch.equal(got_y, ref_y) and torch.equal(got_g['global'], ref_g['global'])
+
+
 def test_unet_forward_mixed_widths(amd, oracle):
     """units=64, depth=3: block widths 128, 128, 256 on the way down (hybrid widths in one model)."""
     shapes = oracle.graph_unet_shapes_for(64, depth=3)
