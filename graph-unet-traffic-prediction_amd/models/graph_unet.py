@@ -78,6 +78,7 @@ class GraphUNet(GraphBaseModel):
             layer.load_weights(flat, prefix, device)
         if 'cnn1/kernel' in flat and 'cnn2/kernel' in flat:
             self.load_frontend_weights(flat, device)
+        self._native_struct = None      # the library's weight table points at the old tensors
         return self
 
     def named_weights(self):
@@ -110,8 +111,14 @@ class GraphUNet(GraphBaseModel):
     def _native_weights(self, c_in, f_e, g, device):
         """The library's weight table for inputs of these widths; layers without loaded weights are
         initialised on the way (Keras defaults), each with the widths the layers before it give."""
-        key = (c_in, f_e, g, str(device))
-        if self._native_struct is not None and self._native_key == key:
+        # rebuilt when a layer's own table was dropped (its load_weights) or the widths change
+        layers = [layer for _, layer in self._gn_layers()]
+        def key():
+            return (c_in, f_e, g, str(device), self.in_layer.kernel is None or self.in_layer.kernel.data_ptr(),
+                    self.out_model.kernel is None or self.out_model.kernel.data_ptr())
+
+        if (self._native_struct is not None and self._native_key == key()
+                and all(layer._struct is not None for layer in layers)):
             return self._native_struct
         s = UNetWeightsStruct()
         keep = []
@@ -150,7 +157,7 @@ class GraphUNet(GraphBaseModel):
         s.out_kernel = self.out_model.kernel.data_ptr()
         s.out_bias = self.out_model.bias.data_ptr() if self.out_model.bias is not None else None
         s._keep = keep
-        self._native_struct, self._native_key = s, key
+        self._native_struct, self._native_key = s, key()
         self._native_widths = (fe, gw)
         return s
 

@@ -159,6 +159,18 @@ def test_unet_forward_mixed_widths(amd, oracle):
     assert torch.equal(got_y, ref_y)
 
 
+def test_unet_reload_weights(amd, oracle):
+    """load_weights after a forward: the next forward uses the new tensors."""
+    x, graph, _ = make_case(oracle, 12, 16, 0.6)
+    model = None
+    for seed in (1, 2):
+        W = oracle.make_weights(oracle.graph_unet_shapes(), seed)
+        model = _model(amd, W) if model is None else model.load_weights(W, 'cuda')
+        want_y, _ = oracle.graph_unet_forward(x, copy_graph(graph), W)
+        got_y, _ = model(to_dev(x), graph_to_dev(graph))
+        assert rel_err(got_y.cpu().numpy(), want_y) <= TOL, seed
+
+
 def test_unet_forward_errors(amd, oracle):
     from gunet_amd import _lib, plan
     W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
