@@ -260,6 +260,8 @@ def main():
             'nodes_per_level': n_levels, 'quadrant_edges_per_level': e_levels, 'batch_per_gpu': B,
             'parallelism': f'replicas x{world}, batch-sharded' + (', RCCL gather of outputs to rank 0 + metrics all-reduce per step' if world > 1 else ''),
             'forward': 'one gunet_unet_forward_f32 call per step over a cached gunet_plan',
+            'workspace_GB': (lambda w: None if w is None else w.numel() / 1e9)(
+                gunet_amd.plan._model_workspaces.get((dev.type, dev.index))),
             'plan': 'cached', 'plan_build_ms_first_call': first_call_ms, 'quadrant_partition_ms': partition_ms,
             'gflop_per_sample': work['total_flops'] / 1e9, 'executed_gflop_per_sample': work['total_flops_executed'] / 1e9,
             'compulsory_GB_per_sample': work['compulsory_bytes'] / 1e9,
