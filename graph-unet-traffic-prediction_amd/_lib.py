@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgunet_hip.so')
+# GUNET_HIP_LIBRARY: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get('GUNET_HIP_LIBRARY') or os.path.join(_HERE, 'libgunet_hip.so')
 
 ACT_LINEAR = 0
 ACT_RELU = 1
