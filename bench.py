@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument('--min-units', type=int, default=128, choices=[128, 256],
                     help='width of every block (128 = the shipped checkpoint; 256 = the wide stress variant)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-runs', type=int, default=3)
+    ap.add_argument('--cpu-runs', type=int, default=7, help='timed CPU forwards (about 1.5 s each)')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel event pass')
     ap.add_argument('--no-alt-modes', action='store_true', help='skip the short bf16-operand run reported beside the result')
     ap.add_argument('--matmul', default=os.environ.get('GUNET_BENCH_MATMUL', 'f32'), choices=['f32', 'split3', 'split2', 'bf16'],
