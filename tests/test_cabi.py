@@ -25,6 +25,34 @@ def test_library_exports_declared_symbols():
     assert gunet_amd._lib.last_error() == ''
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/gunet_hip.h compiles as C99 on its own, a C caller links against the library, and the
+    structs have the layout the ctypes table assumes."""
+    import subprocess
+    import gunet_amd
+    from gunet_amd import _lib
+    src = tmp_path / 'use_header.c'
+    src.write_text('''
+#include "gunet_hip.h"
+#include <stdio.h>
+int main(void) {
+  gunet_unet_weights w;
+  gunet_quadgraph g;
+  printf("%zu %zu %zu %d\\n", sizeof(g), sizeof(w.down[0]), sizeof(w), gunet_version());
+  return gunet_plan_depth((const gunet_plan*)0) == GUNET_ERR_INVALID ? 0 : 1;
+}
+''')
+    exe = tmp_path / 'use_header'
+    libdir = os.path.dirname(gunet_amd.LIB_PATH)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'), str(src),
+                    '-o', str(exe), '-L', libdir, '-l:libgunet_hip.so', f'-Wl,-rpath,{libdir}',
+                    '-Wl,--allow-shlib-undefined'], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out[:3]] == [ctypes.sizeof(_lib.QuadGraphStruct), ctypes.sizeof(_lib.GnWeightsStruct),
+                                         ctypes.sizeof(_lib.UNetWeightsStruct)]
+    assert int(out[3]) >= 1
+
+
 def test_mirror_keeps_reference_names():
     import gunet_amd
     from gunet_amd.layers import hybrid_gnn, graph_ops, get, LAYERS
