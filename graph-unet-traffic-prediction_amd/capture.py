@@ -1,9 +1,11 @@
 """Replay of a whole forward as one HIP graph (no counterpart in the reference, whose TF2 path
-wraps the same call in tf.function).  A forward is ~110 kernel launches; for one or two samples
-the host cannot issue them as fast as the GPU retires them, and a captured graph removes that
-limit.  Shapes, the city graph and the weights are frozen at capture; the inputs are copied into
+wraps the same call in tf.function): for callers that want a forward as a single graph launch,
+or that drive the per-layer mirrors from Python, where for one or two samples the host cannot
+issue the ~110 launches as fast as the GPU retires them.  Shapes, the city graph and the weights are frozen at capture; the inputs are copied into
 static buffers before every replay."""
 import torch
+
+from . import plan as _plan
 
 
 class CapturedForward:
@@ -21,16 +23,18 @@ class CapturedForward:
         self.glob = graph['global'].clone()
         self.edge_index = list(graph['edge_index'])
         self.node_loc = graph['node_loc']
+        self.scratch = _plan.WorkspaceScope()               # the graph's own scratch, alive as long as it is
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(side):                       # builds every plan and workspace first
-            for _ in range(max(1, warmup)):
-                self._run()
-        torch.cuda.current_stream(x.device).wait_stream(side)
-        torch.cuda.synchronize(x.device)
-        self.hip_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.hip_graph):
-            self.y = self._run()
+        with self.scratch:
+            with torch.cuda.stream(side):                   # builds every plan and workspace first
+                for _ in range(max(1, warmup)):
+                    self._run()
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            torch.cuda.synchronize(x.device)
+            self.hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.hip_graph):
+                self.y = self._run()
 
     def _run(self):
         g = {'edge_index': list(self.edge_index), 'edges': list(self.edges), 'node_loc': self.node_loc,

@@ -305,28 +305,43 @@ def get_unet_plan(node_loc, edge_index, depth):
 
 
 _workspaces = {}
+_model_workspaces = {}
+_scopes = []
+
+
+class WorkspaceScope:
+    """Scratch buffers of their own for everything run inside `with scope:`.  The shared per-device
+    buffers below are replaced by a larger allocation when a later call needs more, which would
+    pull the memory from under a captured HIP graph; a capture runs inside a scope and keeps it."""
+
+    def __init__(self):
+        self.layer, self.model = {}, {}
+
+    def __enter__(self):
+        _scopes.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _scopes.remove(self)
+        return False
+
+
+def _grown(table, nbytes, device, slack):
+    key = (device.type, device.index)
+    buf = table.get(key)
+    if buf is None or buf.numel() < nbytes:
+        table[key] = None            # let go of the old buffer before asking for the new one
+        buf = torch.empty(int(nbytes * slack) + 256, dtype=torch.uint8, device=device)
+        table[key] = buf
+    return buf
 
 
 def workspace(nbytes, device):
     """A per-device scratch buffer that only grows; kernels on one stream reuse it in order."""
-    key = (device.type, device.index)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
-    return buf
-
-
-_model_workspaces = {}
+    return _grown(_scopes[-1].layer if _scopes else _workspaces, nbytes, device, 1.25)
 
 
 def model_workspace(nbytes, device):
     """Per-device buffer of the whole-model entry point (all intermediates of one forward, skip
     tensors included); grows to the largest request and is reused in stream order."""
-    key = (device.type, device.index)
-    buf = _model_workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _model_workspaces[key] = None
-        buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
-        _model_workspaces[key] = buf
-    return buf
+    return _grown(_scopes[-1].model if _scopes else _model_workspaces, nbytes, device, 1.0)

@@ -443,3 +443,17 @@ def test_captured_forward(amd, oracle):
     eager2 = model.predict(x2, g2).clone()
     assert torch.equal(cap(x2, glob=glob2), eager2)
     assert torch.equal(cap(xt, glob=g['global']), eager)
+    # a later, larger forward replaces the shared scratch buffers; the graph has its own
+    big = dict(g)
+    big['edges'] = [e.unsqueeze(0).repeat(6, 1, 1) for e in g['edges']]
+    big['global'] = g['global'].repeat(6, 1)
+    yb = model.predict(xt.unsqueeze(0).repeat(6, 1, 1), big)
+    junk = torch.full((1 << 22,), float('nan'), device='cuda')
+    assert torch.equal(yb[3], eager)
+    assert torch.equal(cap(xt, glob=g['global']), eager)
+    del junk
+    # the per-layer mirrors captured the same way
+    model.native_forward = False
+    cap2 = amd.CapturedForward(model, xt, g)
+    model.native_forward = True
+    assert torch.equal(cap2(x2, glob=glob2), eager2)
