@@ -159,6 +159,26 @@ def test_unet_forward_mixed_widths(amd, oracle):
     assert torch.equal(got_y, ref_y)
 
 
+def test_unet_forward_repeatable_full_size(amd, oracle):
+    """495x436 road graph, batch 3, thirty forwards: every run and every batch row of identical
+    inputs gives the same bits (no atomics or launch-order dependence anywhere on the path)."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(495, 436, 0.45, 0)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    enc = oracle.synth_street_encoding(node_loc.shape[0], 5)
+    sn, te, wd = oracle.synth_sample(node_loc, quads, 77, time_idx=3, weekday=2)
+    x, graph = oracle.assemble_inputs(sn, enc, quads, node_loc, te, wd)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    g = graph_to_dev(graph)
+    g['edges'] = [e.unsqueeze(0).repeat(3, 1, 1) for e in g['edges']]
+    g['global'] = g['global'].repeat(3, 1)
+    xd = to_dev(x).unsqueeze(0).repeat(3, 1, 1)
+    first = model.predict(xd, dict(g)).clone()
+    assert torch.equal(first[0], first[1]) and torch.equal(first[0], first[2])
+    for _ in range(30):
+        assert torch.equal(model.predict(xd, dict(g)), first)
+
+
 def test_unet_reload_weights(amd, oracle):
     """load_weights after a forward: the next forward uses the new tensors."""
     x, graph, _ = make_case(oracle, 12, 16, 0.6)
