@@ -198,9 +198,10 @@ class GraphUNet(GraphBaseModel):
         scratch = _plan.model_workspace(nbytes, dev)
         base = (scratch.data_ptr() + 255) // 256 * 256
         in_ptrs, out_ptrs = ptr4(feats), ptr4(edges_out)
-        call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
-             _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs), ptr(global_out),
-             C.c_void_p(base), scratch.numel() - (base - scratch.data_ptr()), current_stream(dev))
+        with torch.cuda.device(dev):     # kernels go to the current device; the plan checks that it is its own
+            call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
+                 _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs), ptr(global_out),
+                 C.c_void_p(base), scratch.numel() - (base - scratch.data_ptr()), current_stream(dev))
         if single:
             out = out[0]
             edges_out = [e[0] for e in edges_out]
