@@ -145,6 +145,40 @@ def test_unet_forward_tiny_graphs(amd, oracle, size):
     assert torch.equal(got_y, ref_y) and torch.equal(got_g['global'], ref_g['global'])
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_unet_forward_random_shapes(amd, oracle, seed):
+    """Random image sizes (tall, wide, odd), densities and batch sizes; depth 2 or 3."""
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    h, w = int(rng.integers(5, 70)), int(rng.integers(5, 70))
+    density = float(rng.uniform(0.3, 0.9))
+    depth = int(rng.integers(2, 4))
+    batch = int(rng.integers(1, 4))
+    shapes = oracle.graph_unet_shapes(depth=depth)
+    W = oracle.make_weights(shapes, 10 + seed)
+    model = _model(amd, W, depth=depth)
+    x, graph, _ = make_case(oracle, h, w, density, graph_seed=seed)
+    node_loc, quads = graph['node_loc'], graph['edge_index']
+    enc = oracle.synth_street_encoding(node_loc.shape[0], 5)
+    xs, graphs = [], []
+    for b in range(batch):
+        sn, te, wd = oracle.synth_sample(node_loc, quads, 500 + 10 * seed + b, time_idx=b, weekday=b)
+        xb, gb = oracle.assemble_inputs(sn, enc, quads, node_loc, te, wd)
+        xs.append(xb)
+        graphs.append(gb)
+    g = graph_to_dev(graphs[0])
+    g['edges'] = [torch.stack([to_dev(gr['edges'][q]) for gr in graphs]) for q in range(4)]
+    g['global'] = torch.cat([to_dev(gr['global']) for gr in graphs], dim=0)
+    xd = torch.stack([to_dev(v) for v in xs])
+    got_y, got_g = model(xd, dict(g))
+    for b in range(batch):
+        want_y, want_g = oracle.graph_unet_forward(xs[b], copy_graph(graphs[b]), W, depth=depth)
+        assert rel_err(got_y[b].cpu().numpy(), want_y) <= TOL, (h, w, depth, b)
+        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
+    model.native_forward = False
+    ref_y, ref_g = model(xd, dict(g))
+    assert torch.equal(got_y, ref_y) and torch.equal(got_g['global'], ref_g['global'])
+
+
 def test_unet_forward_mixed_widths(amd, oracle):
     """units=64, depth=3: block widths 128, 128, 256 on the way down (hybrid widths in one model)."""
     shapes = oracle.graph_unet_shapes_for(64, depth=3)
