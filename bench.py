@@ -8,8 +8,8 @@ One "step" = one forward of the batch with inputs resident in HBM and the per-ci
 cached (the plan build is timed separately and reported in `config`).
 
 With --gpus N > 1 every rank runs its own batch (weak scaling, no collective inside the forward);
-per step the predictions are gathered on rank 0 and a small metrics vector is all-reduced over
-RCCL, overlapped with the next step.
+per step the predictions are gathered on one rank (the collector rotates) and a small metrics vector
+is all-reduced over RCCL, overlapped with the next step.
 
 Prints ONE JSON line on rank 0.
 """
@@ -168,7 +168,13 @@ def main():
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - t0) * 1e3
 
-    exchange = sharding.StepExchange(y)
+    # every step's predictions are collected on one rank; the collector rotates (step i -> rank
+    # i % world) so that no single GPU's links and memory take all of them
+    exchange = sharding.StepExchange(y, rotate=True)
+    if world > 1:   # first use of every sender -> collector route, outside the warm-up and the timed steps
+        for i in range(world):
+            exchange.post(i, y, torch.zeros(2, dtype=torch.float64, device=dev))
+        exchange.drain()
 
     def step(i):
         y = forward()
@@ -258,7 +264,7 @@ def main():
                          f'one {args.height}x{args.width} ' + ('dense grid' if args.dense else f'road graph (density {args.density}, seed 0)')
                          + f', batch {B} per GPU'),
             'nodes_per_level': n_levels, 'quadrant_edges_per_level': e_levels, 'batch_per_gpu': B,
-            'parallelism': f'replicas x{world}, batch-sharded' + (', RCCL gather of outputs to rank 0 + metrics all-reduce per step' if world > 1 else ''),
+            'parallelism': f'replicas x{world}, batch-sharded' + (', RCCL gather of outputs to a rotating collector rank + metrics all-reduce per step' if world > 1 else ''),
             'forward': 'one gunet_unet_forward_f32 call per step over a cached gunet_plan',
             'workspace_GB': (lambda w: None if w is None else w.numel() / 1e9)(
                 gunet_amd.plan._model_workspaces.get((dev.type, dev.index))),

@@ -72,20 +72,25 @@ def sum_metrics(values, group=None):
 
 
 class StepExchange:
-    """What a multi-GPU run exchanges per step: the predictions of every rank gathered on rank 0 and
+    """What a multi-GPU run exchanges per step: the predictions of every rank gathered on one rank and
     a small metrics vector summed over the ranks.  Both are posted asynchronously and double-buffered
     (step i uses slot i & 1 and first waits for step i - 2 in that slot), so the transfers of one
-    step overlap the forward of the next.  With one rank nothing is posted."""
+    step overlap the forward of the next.  With `rotate` the collecting rank of step i is i % world
+    instead of always rank 0: every GPU then receives (world - 1) / world of one step's predictions
+    per step on average, instead of one GPU's links and memory taking all of them while the others
+    wait for it at the next barrier.  With one rank nothing is posted."""
 
-    def __init__(self, like, group=None):
+    def __init__(self, like, group=None, rotate=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.rotate = rotate
         self.out = [torch.empty_like(like) for _ in range(2)] if self.world > 1 else None
         self.gathered = [None, None]
-        if self.world > 1 and self.rank == 0:
+        if self.world > 1 and (rotate or self.rank == 0):
             self.gathered = [torch.empty((self.world,) + tuple(like.shape), dtype=like.dtype, device=like.device)
                              for _ in range(2)]
+        self.collector = [None, None]     # which rank holds the gathered predictions of each slot
         self.metrics = [None, None]
         self.pending = [None, None]
 
@@ -97,9 +102,11 @@ class StepExchange:
         self.wait(slot)
         self.out[slot].copy_(y)
         self.metrics[slot] = metrics
+        dst = step % self.world if self.rotate else 0
+        self.collector[slot] = dst
         works = [dist.all_reduce(metrics, group=self.group, async_op=True)]
-        gather_list = list(self.gathered[slot].unbind(0)) if self.rank == 0 else None
-        works.append(dist.gather(self.out[slot], gather_list=gather_list, dst=0, group=self.group, async_op=True))
+        gather_list = list(self.gathered[slot].unbind(0)) if self.rank == dst else None
+        works.append(dist.gather(self.out[slot], gather_list=gather_list, dst=dst, group=self.group, async_op=True))
         self.pending[slot] = works
 
     def wait(self, slot):

@@ -49,6 +49,17 @@ def _worker(rank, world, port, out_dir):
             assert torch.equal(ex.gathered[i & 1], want), i
     for i in (3, 4):
         assert ex.metrics[i & 1].tolist() == [float(i * world), float(sum(range(world)))]
+    # rotating collector: step i is gathered on rank i % world
+    ex = sharding.StepExchange(torch.zeros((3, 4)), rotate=True)
+    for i in range(6):
+        ex.post(i, torch.full((3, 4), float(10 * i + rank)), torch.tensor([1.0], dtype=torch.float64))
+    ex.drain()
+    for i in (4, 5):
+        assert ex.collector[i & 1] == i % world
+        if rank == i % world:
+            want = torch.stack([torch.full((3, 4), float(10 * i + r)) for r in range(world)])
+            assert torch.equal(ex.gathered[i & 1], want), i
+        assert ex.metrics[i & 1].tolist() == [float(world)]
     dist.barrier()
     dist.destroy_process_group()
 
