@@ -1,0 +1,120 @@
+// Internal interface of the GEMM kernels (gemm_ops.hip) for the layer code (feature_ops.hip).
+#pragma once
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace gunet {
+
+// out[b, map(r), :] = act( sum_s A_s[b, r, :] @ W_s + bias[b] ),  r < n_rows, for up to three operand
+// segments that are concatenated along K in the reference (x | aggregated messages, or
+// upsampled x | skip x | aggregated messages).  One workgroup = 128 rows x (32*NT) columns,
+// four waves of 32 rows each; K is consumed in tiles of 32.
+struct GemmSeg {
+  const float* a;      // sample 0, row 0
+  int lda;             // row stride (floats); sample stride is n_rows * lda
+  int k;               // width of this segment (multiple of 4)
+  const float* w[4];   // weights of column tile t: element [k][j] at w[t][k * ldw + j], j < 32
+  int ldw;
+};
+
+struct GemmArgs {
+  GemmSeg seg[3];
+  int n_seg;
+  int n_rows;                 // A rows per sample
+  const float* bias;          // [.., 32*NT] or null
+  int bias_stride;            // floats between samples (0 = shared)
+  float* out;                 // sample 0; null = compute the column sums only
+  int ldo;
+  int out_col0;               // first output column of this launch
+  int out_rows;               // rows per sample of the output tensor
+  const int32_t* row_map;     // A row r -> output row row_map[r * row_map_stride] - row_map_sub
+  int row_map_stride;         //   (null = identity)
+  int row_map_sub;
+  float* colsum;              // partial column sums of the activated output, or null:
+  int colsum_tiles;           //   [B][colsum_tiles][colsum_ld], this launch fills rows colsum_tile0 ..
+  int colsum_tile0;           //   colsum_tile0 + gemm_colsum_rows() - 1 (one per workgroup or per wave)
+  int colsum_ld;              //   floats (0 = 32*NT), this launch's columns start at out_col0
+  int relu;
+  // Gathered last segment (weights-resident kernel only): when gather_table is set, the last
+  // segment (k = 128) is not read from seg[].a; row v's column block q is formed while loading as
+  // gather_scale * (sum over j of row gather_table[(v * 4 + q) * 3 + j] (>= 0, in that order) of
+  // gather_src[q], a [B][gather_rows[q]][32] tensor).
+  const int32_t* gather_table;
+  const float* gather_src[4];
+  int gather_rows[4];
+  float gather_scale;
+};
+
+constexpr int kBM = 128;
+constexpr int kBK = 32;
+constexpr int kRowGroup = 32;   // rows of one wave = rows of one column-sum partial
+
+constexpr int kMaxCin = 1024;    // widest layer input the workspaces are sized for
+constexpr int kMaxUT = 2;        // widest layer: 128 * kMaxUT columns
+
+inline int gemm_ktiles(const GemmArgs& g) {
+  int n = 0;
+  for (int s = 0; s < g.n_seg; ++s) n += (g.seg[s].k + kBK - 1) / kBK;
+  return n;
+}
+
+// Bytes of weight image a launch of `ktiles` K tiles and `nt` column tiles needs in the split modes.
+inline size_t wpack_bytes(int ktiles, int nt) {
+  return static_cast<size_t>(ktiles) * 3 * 4 * 32 * nt * sizeof(uint4);
+}
+
+bool bf16_mode();        // gunet_set_matmul_mode(GUNET_MATMUL_BF16) is in force
+int device_cu_count();   // compute units of the current device
+
+// Which kernel family a launch gets, and how many column-sum partial rows per sample it writes.
+bool takes_resident(const GemmArgs& g, int nt, int64_t batch, const void* wpack);
+int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack);
+
+// One GEMM of 32 * nt columns (wpack: scratch of wpack_bytes(gemm_ktiles(g), nt) for the split
+// modes, may be null in GUNET_MATMUL_F32 mode); several problems of equal nt as one launch.
+int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stream);
+int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wpack, hipStream_t stream);
+
+// GEMM with U output columns as U/128 launches of 128 columns.  `w_of(s, col)` gives the weight
+// pointer of segment s for the 32-column tile starting at output column `col`.
+template <typename WeightOf>
+GemmArgs columns_block(const GemmArgs& g, int units, int col0, int nt, const float* bias, int bias_stride, float* out,
+                       float* colsum, WeightOf w_of) {
+  GemmArgs gc = g;
+  for (int s = 0; s < g.n_seg; ++s)
+    for (int t = 0; t < nt; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
+  gc.bias = bias ? bias + col0 : nullptr;
+  gc.bias_stride = bias_stride;
+  gc.out = out;
+  gc.ldo = units;
+  gc.out_col0 = col0;
+  gc.colsum = colsum;
+  gc.colsum_ld = units;
+  return gc;
+}
+
+// Column tiles per launch: 128 columns, except 64 for the gathering GEMM with three operand
+// segments (its weights fill LDS at that width).
+inline int columns_nt(const GemmArgs& g) {
+  return (g.gather_table != nullptr && gemm_ktiles(g) == 12 && !bf16_mode()) ? 2 : 4;
+}
+
+// Column-sum partial rows per sample such a GEMM writes (the same for each of its column blocks).
+inline int columns_colsum_rows(const GemmArgs& g, int units, int64_t batch, const void* wpack) {
+  GemmArgs gc = g;
+  gc.ldo = units;
+  return gemm_colsum_rows(gc, columns_nt(g), batch, wpack);
+}
+
+template <typename WeightOf>
+int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
+                        float* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
+  const int nt = columns_nt(g);
+  for (int col0 = 0; col0 < units; col0 += 32 * nt)
+    GUNET_TRY(launch_gemm(columns_block(g, units, col0, nt, bias, bias_stride, out, colsum, w_of), nt, batch, wpack, stream));
+  return GUNET_OK;
+}
+
+}  // namespace gunet
