@@ -129,7 +129,7 @@ def test_unet_forward_one_call(amd, oracle, size, batch):
     assert rel_err(y1.cpu().numpy(), oracle.graph_unet_forward(xs[0], copy_graph(graphs[0]), W)[0]) <= TOL
 
 
-@pytest.mark.parametrize('size', [(2, 2), (3, 5), (1, 7), (5, 4)])
+@pytest.mark.parametrize('size', [(1, 2), (2, 2), (3, 5), (1, 7), (5, 4)])
 def test_unet_forward_tiny_graphs(amd, oracle, size):
     """Graphs that run out of edges (and nearly of nodes) on the way down: the deeper levels have a
     single node or no edges at all in some or all quadrants."""
