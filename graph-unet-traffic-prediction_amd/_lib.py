@@ -49,6 +49,7 @@ class GnWeightsStruct(C.Structure):
 
 
 MAX_DEPTH = 8
+STATIC_SCRATCH_BYTES = 64 << 20      # GUNET_STATIC_SCRATCH_BYTES
 
 
 class UNetWeightsStruct(C.Structure):
@@ -120,6 +121,9 @@ SIGNATURES = {
     'gunet_unet_forward_f32': (C.c_int, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32, C.c_void_p,
                                          C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                          C.POINTER(VoidP4), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'gunet_unet_forward_static_f32': (C.c_int, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32, C.c_void_p,
+                                                C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                C.POINTER(VoidP4), C.c_void_p, C.c_void_p]),
     'gunet_street_encoding_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_void_p, C.c_void_p]),
     'gunet_edge_features_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,

@@ -6,6 +6,7 @@
 //   gunet_unet_forward_f32  models/graph_unet.py:61-84 GraphUNet.call as one asynchronous,
 //                           allocation-free call over caller workspace: the same kernels in the same
 //                           order as the layer-by-layer entry points, so results are bit-identical.
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -318,6 +319,37 @@ int carve_model(const char* who, const gunet_plan* P, const gunet_unet_weights* 
   return GUNET_OK;
 }
 
+int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
+                 const float* const edges[4], const float* global_in, int32_t activation, int32_t out_activation,
+                 float* out, float* const edges_out[4], float* global_out, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream);
+
+// Intermediates of gunet_unet_forward_static_f32: one array per GPU, alive from the loading of the
+// code object to the end of the process, shared by every call on that GPU.  In host code the
+// array's name is only a handle for hipGetSymbolAddress; the device address it yields (one per
+// device) is what kernels and memsets are given.
+constexpr size_t kStaticScratchBytes = GUNET_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+
+// Device address of `scratch` on device `dev`, which must be the current device.  Looked up once
+// per device.
+int static_scratch_of(int dev, void** out) {
+  static std::mutex lock;
+  static void* address[kMaxDevices] = {};
+  GUNET_REQUIRE(dev >= 0 && dev < kMaxDevices, "static scratch: device index %d", dev);
+  std::lock_guard<std::mutex> hold(lock);
+  if (address[dev] == nullptr) {
+    void* p = nullptr;
+    GUNET_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    GUNET_REQUIRE(p != nullptr && reinterpret_cast<uintptr_t>(p) % 256 == 0, "static scratch: bad symbol address");
+    address[dev] = p;
+  }
+  *out = address[dev];
+  return GUNET_OK;
+}
+
 }  // namespace
 }  // namespace gunet
 
@@ -394,8 +426,44 @@ size_t gunet_unet_workspace_bytes(const gunet_plan* plan, const gunet_unet_weigh
 int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
                            const float* const edges[4], const float* global_in, int32_t activation,
                            int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
-                           void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
-  hipStream_t stream = as_stream(stream_);
+                           void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
+  return unet_forward(P, w, batch, x, edges, global_in, activation, out_activation, out, edges_out, global_out,
+                      workspace, workspace_bytes, as_stream(stream));
+}
+
+int gunet_unet_forward_static_f32(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
+                                  const float* const edges[4], const float* global_in, int32_t activation,
+                                  int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
+                                  gunet_stream_t stream) {
+  GUNET_REQUIRE(P && w, "unet_forward_static: null plan or weights");
+  GUNET_REQUIRE(batch > 0, "unet_forward_static: batch %d", batch);
+  ModelBuffers mb;
+  int final_width = 0;
+  GUNET_TRY(carve_model("unet_forward_static", P, w, batch, nullptr, &mb, &final_width));
+  if (mb.bytes > kStaticScratchBytes) {
+    set_error("unet_forward_static: this graph and batch need %zu bytes of intermediates, the library's static scratch "
+              "buffer holds %zu (use gunet_unet_forward_f32 with a caller workspace)", mb.bytes, kStaticScratchBytes);
+    return GUNET_ERR_WORKSPACE;
+  }
+  int dev = 0;
+  GUNET_HIP_TRY(hipGetDevice(&dev));
+  GUNET_REQUIRE(dev == P->device, "unet_forward_static: the plan lives on device %d, the current device is %d",
+                P->device, dev);
+  void* base = nullptr;
+  GUNET_TRY(static_scratch_of(dev, &base));
+  return unet_forward(P, w, batch, x, edges, global_in, activation, out_activation, out, edges_out, global_out, base,
+                      kStaticScratchBytes, as_stream(stream));
+}
+
+}  // extern "C"
+
+namespace gunet {
+namespace {
+
+int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
+                 const float* const edges[4], const float* global_in, int32_t activation, int32_t out_activation,
+                 float* out, float* const edges_out[4], float* global_out, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream) {
   GUNET_REQUIRE(P && w, "unet_forward: null plan or weights");
   GUNET_REQUIRE(batch > 0, "unet_forward: batch %d", batch);
   GUNET_REQUIRE(x && edges && global_in && out, "unet_forward: null tensor");
@@ -547,4 +615,5 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
                                  out_activation, out, mb.layer_ws, mb.layer_ws_bytes, stream);
 }
 
-}  // extern "C"
+}  // namespace
+}  // namespace gunet

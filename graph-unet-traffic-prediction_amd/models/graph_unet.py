@@ -55,6 +55,10 @@ class GraphUNet(GraphBaseModel):
         # model is the plain stack of GeoQuadrantGCN layers; False walks the layer objects instead
         # (same kernels in the same order, identical results).
         self.native_forward = True
+        # True: the one-call forward keeps its intermediates in the library's static scratch buffer
+        # (gunet_unet_forward_static_f32) instead of a torch-allocated workspace; graphs whose
+        # intermediates exceed _lib.STATIC_SCRATCH_BYTES raise GunetError.
+        self.static_scratch = False
         self._native_struct = None
         self._native_key = None
 
@@ -195,13 +199,18 @@ class GraphUNet(GraphBaseModel):
         nbytes = int(_lib.lib.gunet_unet_workspace_bytes(up.handle, C.byref(ws), batch))
         if nbytes == 0:
             raise NotImplementedError(f'GraphUNet: {_lib.last_error()}')
-        scratch = _plan.model_workspace(nbytes, dev)
-        base = (scratch.data_ptr() + 255) // 256 * 256
         in_ptrs, out_ptrs = ptr4(feats), ptr4(edges_out)
         with torch.cuda.device(dev):     # kernels go to the current device; the plan checks that it is its own
-            call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
-                 _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs), ptr(global_out),
-                 C.c_void_p(base), scratch.numel() - (base - scratch.data_ptr()), current_stream(dev))
+            if self.static_scratch:
+                call('gunet_unet_forward_static_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs),
+                     ptr(glob), _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs),
+                     ptr(global_out), current_stream(dev))
+            else:
+                scratch = _plan.model_workspace(nbytes, dev)
+                base = (scratch.data_ptr() + 255) // 256 * 256
+                call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
+                     _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs), ptr(global_out),
+                     C.c_void_p(base), scratch.numel() - (base - scratch.data_ptr()), current_stream(dev))
         if single:
             out = out[0]
             edges_out = [e[0] for e in edges_out]

@@ -300,6 +300,22 @@ int gunet_unet_forward_f32(const gunet_plan* plan, const gunet_unet_weights* wei
                            float* const edges_out[4], float* global_out, void* workspace,
                            size_t workspace_bytes, gunet_stream_t stream);
 
+/* gunet_unet_forward_f32 for callers that cannot allocate device memory and have no workspace to
+ * hand in: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  Same arguments, kernels and results as gunet_unet_forward_f32,
+ * except that the intermediates live in a buffer of GUNET_STATIC_SCRATCH_BYTES that is part of the
+ * library's device image: every GPU the library runs on holds one from the loading of the library
+ * to the end of the process.  The call allocates and frees nothing.  A graph and batch whose
+ * intermediates do not fit (gunet_unet_workspace_bytes(plan, weights, batch) >
+ * GUNET_STATIC_SCRATCH_BYTES) are refused with GUNET_ERR_WORKSPACE before anything is launched.
+ * All calls on one GPU share that GPU's buffer: calls that overlap in time on the same GPU (two
+ * streams, two host threads) race; calls on one stream, or ordered by events, are safe. */
+#define GUNET_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
+int gunet_unet_forward_static_f32(const gunet_plan* plan, const gunet_unet_weights* weights, int32_t batch,
+                                  const float* x, const float* const edges[4], const float* global_in,
+                                  int32_t activation, int32_t out_activation, float* out,
+                                  float* const edges_out[4], float* global_out, gunet_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 3. Either side of the model -- graph construction, input assembly (models/base_model.py:274-312),
  *    prediction image and metric sums (asynchronous and allocation-free except gunet_image_to_graph)
