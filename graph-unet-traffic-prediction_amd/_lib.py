@@ -117,6 +117,9 @@ SIGNATURES = {
     'gunet_plan_pooling': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(VoidP4)]),
     'gunet_plan_upsampling': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QuadGraphStruct),
                                         C.POINTER(C.c_void_p)]),
+    'gunet_plan_pool_features_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                               C.POINTER(VoidP4), C.c_int32, C.c_void_p, C.POINTER(VoidP4),
+                                               C.c_void_p]),
     'gunet_unet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32]),
     'gunet_unet_forward_f32': (C.c_int, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32, C.c_void_p,
                                          C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

@@ -107,6 +107,29 @@ class ProfScope {
 
 inline hipStream_t as_stream(gunet_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// Every entry point that takes a stream runs on that stream's device: when it is not the current
+// one (one process driving several GPUs), the guard makes it current for the length of the call, so
+// launches, temporary allocations and plan ownership all land on the GPU the stream belongs to.
+// The null stream belongs to whatever device is current.
+class StreamDeviceGuard {
+ public:
+  explicit StreamDeviceGuard(hipStream_t stream) {
+    int current = 0, wanted = 0;
+    if (stream != nullptr && hipGetDevice(&current) == hipSuccess &&
+        hipStreamGetDevice(stream, &wanted) == hipSuccess && wanted != current &&
+        hipSetDevice(wanted) == hipSuccess)
+      previous_ = current;
+  }
+  ~StreamDeviceGuard() {
+    if (previous_ >= 0) (void)hipSetDevice(previous_);
+  }
+  StreamDeviceGuard(const StreamDeviceGuard&) = delete;
+  StreamDeviceGuard& operator=(const StreamDeviceGuard&) = delete;
+
+ private:
+  int previous_ = -1;
+};
+
 // Exclusive prefix sum of `n` int32 values into out[0..n] (n + 1 entries; out[n] = total).
 // `in` and `out` may not alias.  Allocates its own block-sum scratch.
 int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, hipStream_t stream);

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(AggArgs a) {
 constexpr int kPreGlobT = 8;   // rows of the glob_transform product fetched ahead, per thread (head != nullptr)
 
 template <int UT>
-__device__ __forceinline__ void global_update_body(const LayerPtrs& p, const float* __restrict__ npart, int n_nblk,
+__device__ __forceinline__ void global_update_body(const LayerPtrs& p, const double* __restrict__ npart, int n_nblk,
                                                    const float* __restrict__ epart, int n_eblk, int relu, int64_t b,
                                                    double* dpart, float* part, float* gin,
                                                    float* __restrict__ global_out, float* keep,
@@ -685,26 +685,30 @@ __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const flo
   const int sub = tid / QC, cq = tid % QC;
   {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const float4* src = reinterpret_cast<const float4*>(npart + b * n_nblk * static_cast<int64_t>(U)) + cq;
+    const double2* src = reinterpret_cast<const double2*>(npart + b * n_nblk * static_cast<int64_t>(U)) + 2 * cq;
+    constexpr int QD = U / 2;   // double2 per partial row
     int i = sub;
-    for (; i + 7 * S < n_nblk; i += 8 * S) {   // eight partial rows in flight, added in order
-      float4 v[8];
+    for (; i + 3 * S < n_nblk; i += 4 * S) {   // four partial rows in flight, added in order
+      double2 v[4][2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[static_cast<int64_t>(i + j * S) * QC];
+      for (int j = 0; j < 4; ++j) {
+        v[j][0] = src[static_cast<int64_t>(i + j * S) * QD];
+        v[j][1] = src[static_cast<int64_t>(i + j * S) * QD + 1];
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s0 += static_cast<double>(v[j].x);
-        s1 += static_cast<double>(v[j].y);
-        s2 += static_cast<double>(v[j].z);
-        s3 += static_cast<double>(v[j].w);
+      for (int j = 0; j < 4; ++j) {
+        s0 += v[j][0].x;
+        s1 += v[j][0].y;
+        s2 += v[j][1].x;
+        s3 += v[j][1].y;
       }
     }
     for (; i < n_nblk; i += S) {
-      const float4 a = src[static_cast<int64_t>(i) * QC];
-      s0 += static_cast<double>(a.x);
-      s1 += static_cast<double>(a.y);
-      s2 += static_cast<double>(a.z);
-      s3 += static_cast<double>(a.w);
+      const double2 a0 = src[static_cast<int64_t>(i) * QD], a1 = src[static_cast<int64_t>(i) * QD + 1];
+      s0 += a0.x;
+      s1 += a0.y;
+      s2 += a1.x;
+      s3 += a1.y;
     }
     double* d = dpart + sub * U + 4 * cq;
     d[0] = s0;
@@ -774,7 +778,7 @@ __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const flo
 template <int UT>
 __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
                                                                  const float* __restrict__ global_in,
-                                                                 const float* __restrict__ npart, int n_nblk,
+                                                                 const double* __restrict__ npart, int n_nblk,
                                                                  const float* __restrict__ epart, int n_eblk,
                                                                  int relu, float* __restrict__ global_out) {
   extern __shared__ __attribute__((aligned(16))) float gsh[];
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
 // cat_out.
 template <int UTC, int UTN>
 __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, const float* __restrict__ global_in,
-                                                                 const float* __restrict__ npart, int n_nblk,
+                                                                 const double* __restrict__ npart, int n_nblk,
                                                                  const float* __restrict__ epart, int n_eblk, int relu,
                                                                  float* __restrict__ global_out,
                                                                  const float* __restrict__ extra, int extra_width,
@@ -835,7 +839,7 @@ struct LayerWorkspace {
   float* nbias;   // [U]
   float* ebias;   // [B, U]
   float* gbias;   // [B, U]
-  float* npart;   // [B, n_nblk + 5, U]   column sums per 32-row group
+  double* npart;  // [B, n_nblk + 5, U]   column-sum partials of the node MLP (one row per workgroup or wave)
   float* epart;   // [B, 4, n_eblk, u]
   void* wpack;    // weight image of the GEMM in flight (split-bf16 matmul modes)
   int n_nblk, n_eblk;
@@ -864,7 +868,7 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int unit
   ws.gbias = take(bsz * 128 * kMaxUT);
   ws.xq = take(bsz * n * U);
   ws.agg = take(bsz * n * U);
-  ws.npart = take(bsz * (ws.n_nblk + 5) * U);
+  ws.npart = reinterpret_cast<double*>(take(2 * bsz * (ws.n_nblk + 5) * U));
   ws.epart = take(bsz * 4 * ws.n_eblk * u);
   ws.wpack = take(wpack_bytes((kMaxCin + 128 * kMaxUT) / kBK + 2, 4) / sizeof(float));
   ws.bytes = off;
@@ -1079,6 +1083,7 @@ extern "C" {
 int gunet_get_sender_receiver_f32(const float* x, int64_t n_nodes, int32_t width,
                                   const int32_t* edge_index, int64_t n_edges, float* senders,
                                   float* receivers, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_nodes >= 0 && n_edges >= 0 && width >= 0, "get_sender_receiver: negative size");
   if (n_edges == 0 || width == 0) return GUNET_OK;
   GUNET_REQUIRE(x && edge_index && senders && receivers, "get_sender_receiver: null pointer");
@@ -1101,6 +1106,7 @@ int gunet_get_sender_receiver_f32(const float* x, int64_t n_nodes, int32_t width
 int gunet_segment_max_f32(const float* src, int64_t n_src, int32_t width, const int32_t* rowptr,
                           const int32_t* perm, int64_t n_segments, int32_t batch, float* out,
                           gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_src >= 0 && width >= 0 && n_segments >= 0 && batch >= 0, "segment_max: negative size");
   GUNET_REQUIRE(n_segments == 0 || (rowptr && out), "segment_max: null pointer");
   return launch_segment_reduce<true>(src, n_src, width, rowptr, perm, n_segments, batch, 1.0f, out,
@@ -1110,6 +1116,7 @@ int gunet_segment_max_f32(const float* src, int64_t n_src, int32_t width, const 
 int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const int32_t* rowptr,
                           const int32_t* perm, int64_t n_segments, int32_t batch, float scale,
                           float* out, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_src >= 0 && width >= 0 && n_segments >= 0 && batch >= 0, "segment_sum: negative size");
   GUNET_REQUIRE(n_segments == 0 || (rowptr && out), "segment_sum: null pointer");
   return launch_segment_reduce<false>(src, n_src, width, rowptr, perm, n_segments, batch, scale,
@@ -1126,6 +1133,7 @@ int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weig
                                const float* const edges[4], const float* global_in, int32_t activation,
                                float* x_out, float* const edges_out[4], float* global_out,
                                void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   return gn_layer_run(graph, w, batch, x, x_skip, c_skip, edges, global_in, activation, x_out, edges_out, global_out,
                       workspace, workspace_bytes, 0, nullptr, as_stream(stream));
 }
@@ -1134,6 +1142,7 @@ int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse
                                   int32_t batch, const float* x, const float* global_in, int32_t activation,
                                   float* x_out, float* global_out, void* workspace, size_t workspace_bytes,
                                   gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   return gn_upsample_run(graph, n_coarse, w, batch, x, global_in, activation, x_out, global_out, workspace,
                          workspace_bytes, 0, nullptr, as_stream(stream));
 }

@@ -266,6 +266,7 @@ extern "C" {
 int gunet_street_encoding_f32(const uint8_t* street_map, int32_t height, int32_t width, const float* cnn1_kernel,
                               const float* cnn2_kernel, const int64_t* node_loc, int64_t n_nodes, float* out,
                               gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(height > 0 && width > 0 && n_nodes >= 0, "street_encoding: bad size");
   if (n_nodes == 0) return GUNET_OK;
   GUNET_REQUIRE(street_map && cnn1_kernel && cnn2_kernel && node_loc && out, "street_encoding: null pointer");
@@ -278,6 +279,7 @@ int gunet_street_encoding_f32(const uint8_t* street_map, int32_t height, int32_t
 
 int gunet_edge_features_f32(const float* encoding, int64_t n_nodes, int32_t width, const int32_t* edge_index,
                             int64_t n_edges, float* out, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_nodes >= 0 && n_edges >= 0 && width > 0, "edge_features: bad size");
   if (n_edges == 0) return GUNET_OK;
   GUNET_REQUIRE(encoding && edge_index && out, "edge_features: null pointer");
@@ -297,6 +299,7 @@ int gunet_model_inputs_f32(const float* seed_nodes, int32_t seed_width, const fl
                            const float* time_enc, int32_t time_width, const int32_t* weekday, int64_t n_nodes,
                            int32_t batch, float* x, float* global_out, void* workspace, size_t workspace_bytes,
                            gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_nodes > 0 && batch > 0 && seed_width > 0 && enc_width >= 0 && time_width >= 0,
                 "model_inputs: bad size");
   GUNET_REQUIRE(seed_nodes && (encoding || enc_width == 0) && (time_enc || time_width == 0) && weekday && x &&
@@ -322,6 +325,7 @@ int gunet_model_inputs_f32(const float* seed_nodes, int32_t seed_width, const fl
 int gunet_image_to_graph(const uint8_t* maps, int32_t height, int32_t width, int32_t add_selfloops,
                          int64_t* node_loc, int32_t* edge_index, int64_t* direction, uint8_t* node_mask,
                          int64_t counts_host[2], gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(counts_host != nullptr, "image_to_graph: null counts_host");
   counts_host[0] = counts_host[1] = 0;
@@ -359,6 +363,7 @@ int gunet_prediction_image_u8(const float* pred, int64_t n_nodes, int32_t pred_w
                               const int64_t* node_loc, int32_t height, int32_t width, const int32_t* horizons,
                               int32_t n_horizons, int32_t channels, float scale, uint8_t* out,
                               gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(n_nodes >= 0 && batch > 0 && height > 0 && width > 0 && n_horizons > 0 && channels > 0 &&
                     pred_width >= channels,
@@ -382,6 +387,7 @@ size_t gunet_error_sums_workspace_bytes(int64_t n_rows, int32_t batch, int32_t w
 
 int gunet_error_sums_f32(const float* y_true, const float* y_pred, int64_t n_rows, int32_t width, int32_t batch,
                          double* sums, void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(n_rows > 0 && width > 0 && batch > 0, "error_sums: bad size");
   GUNET_REQUIRE(y_true && y_pred && sums, "error_sums: null pointer");

@@ -32,10 +32,13 @@ struct GemmArgs {
   const int32_t* row_map;     // A row r -> output row row_map[r * row_map_stride] - row_map_sub
   int row_map_stride;         //   (null = identity)
   int row_map_sub;
-  float* colsum;              // partial column sums of the activated output, or null:
+  double* colsum;             // partial column sums of the activated output, or null:
   int colsum_tiles;           //   [B][colsum_tiles][colsum_ld], this launch fills rows colsum_tile0 ..
   int colsum_tile0;           //   colsum_tile0 + gemm_colsum_rows() - 1 (one per workgroup or per wave)
-  int colsum_ld;              //   floats (0 = 32*NT), this launch's columns start at out_col0
+  int colsum_ld;              //   doubles (0 = 32*NT), this launch's columns start at out_col0
+                              //   Every kernel forms the float32 sum of each aligned 32-row group in one
+                              //   fixed order and adds the group sums in float64, so the total does not
+                              //   depend (beyond float64 rounding) on which kernel ran or how it split the rows.
   int relu;
   // Gathered last segment (weights-resident kernel only): when gather_table is set, the last
   // segment (k = 128) is not read from seg[].a; row v's column block q is formed while loading as
@@ -81,7 +84,7 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
 // pointer of segment s for the 32-column tile starting at output column `col`.
 template <typename WeightOf>
 GemmArgs columns_block(const GemmArgs& g, int units, int col0, int nt, const float* bias, int bias_stride, float* out,
-                       float* colsum, WeightOf w_of) {
+                       double* colsum, WeightOf w_of) {
   GemmArgs gc = g;
   for (int s = 0; s < g.n_seg; ++s)
     for (int t = 0; t < nt; ++t) gc.seg[s].w[t] = w_of(s, col0 + 32 * t);
@@ -110,7 +113,7 @@ inline int columns_colsum_rows(const GemmArgs& g, int units, int64_t batch, cons
 
 template <typename WeightOf>
 int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
-                        float* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
+                        double* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
   const int nt = columns_nt(g);
   for (int col0 = 0; col0 < units; col0 += 32 * nt)
     GUNET_TRY(launch_gemm(columns_block(g, units, col0, nt, bias, bias_stride, out, colsum, w_of), nt, batch, wpack, stream));

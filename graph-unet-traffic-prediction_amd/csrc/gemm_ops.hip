@@ -5,6 +5,7 @@
 //     last segment, float32 or bf16 operands;
 //   * k_gemm_split: float32 products from bf16 matrix cores with split operands.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <type_traits>
 
@@ -178,17 +179,17 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const int bx) {
       }
     }
   }
-  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' sums added in order
-    float* red = Stage[0];     // 4 * BN <= 512 floats; the staging tiles are no longer in use
+  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' 32-row sums added in float64
+    double* red = reinterpret_cast<double*>(&Stage[0][0]);   // 4 * BN <= 512 doubles; the staging tiles are no longer in use
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
+      if (lh == 0) red[wave * BN + 32 * n + li] = static_cast<double>(cs[n]);
     }
     __syncthreads();
     if (tid < BN) {
-      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      const double s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
       g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + bx) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
@@ -227,7 +228,7 @@ constexpr int kResWaves = 12;
 constexpr int kResThreads = 64 * kResWaves;
 constexpr int kResGatherWaves = 8;   // the 128-column gathering variant needs more registers per wave
 constexpr int kResGatherThreads = 64 * kResGatherWaves;
-constexpr size_t kResMaxLds = 160 * 1024;
+constexpr size_t kResMaxLds = 160 * 1024;   // most LDS a workgroup may ask for on gfx950; see device_lds_limit()
 
 // BF16 = true: operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16 (float32
 // accumulate and storage); a lane then owns, per 16-wide k step, 8 consecutive floats of its row
@@ -378,12 +379,16 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   const uint32_t ldo = static_cast<uint32_t>(g.ldo);
   float* stage = res_smem + (BF16 ? 16 : 32) * NKT * BN + wave * (16 * 32);
   const int srow = lane >> 3, scol = 4 * (lane & 7);
-  float bias_v[NT], cs[NT];
+  // Column sums: the float32 sum of each group's 32 rows (16 rows per lane in a fixed order, then
+  // the two half-waves), added over the wave's run of groups in float64.
+  float bias_v[NT];
+  double cs[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + 32 * n + li] : 0.0f;
-    cs[n] = 0.0f;
+    cs[n] = 0.0;
   }
+  const bool want_cs = g.colsum != nullptr;
   auto epilogue = [&](auto full_tag, int row0) {
     constexpr bool FULL = decltype(full_tag)::value;
     // this lane's first pick-up row as a 32-bit byte offset; the steps between rows are uniform
@@ -392,6 +397,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
          static_cast<uint32_t>(g.out_col0 + scol)) * 4u;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
+      float gs = 0.0f;   // this lane's 16 rows of column 32n + li
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -400,7 +406,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
           const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;   // row within this half of the tile
           const float v = activate(acc[n][r] + bias_v[n], g.relu);
           stage[rl * 32 + li] = v;
-          if (FULL || row0 + 16 * h + rl < g.n_rows) cs[n] += v;
+          if (FULL || row0 + 16 * h + rl < g.n_rows) gs += v;
         }
         if (has_out) {
 #pragma unroll
@@ -411,6 +417,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
               *reinterpret_cast<float4*>(orow + voff + 128u * n) = v;
           }
         }
+      }
+      if (want_cs) {
+        gs += __shfl_xor(gs, 32);
+        cs[n] += static_cast<double>(gs);
       }
     }
   };
@@ -529,13 +539,11 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     cur = nxt;
   }
   if (g.colsum != nullptr) {
-    float* dst = g.colsum + (static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + slot) * g.colsum_ld +
-                 g.out_col0 + li;
+    double* dst = g.colsum + (static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + slot) * g.colsum_ld +
+                  g.out_col0 + li;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      cs[n] += __shfl_xor(cs[n], 32);
+    for (int n = 0; n < NT; ++n)
       if (lh == 0) dst[32 * n] = cs[n];
-    }
   }
 }
 
@@ -755,16 +763,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
       }
     }
   }
-  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' sums added in order
-    __shared__ float red[4 * BN];
+  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' 32-row sums added in float64
+    __shared__ double red[4 * BN];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) red[wave * BN + 32 * n + li] = cs[n];
+      if (lh == 0) red[wave * BN + 32 * n + li] = static_cast<double>(cs[n]);
     }
     __syncthreads();
     if (tid < BN) {
-      const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      const double s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
       g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + blockIdx.x) * g.colsum_ld + g.out_col0 + tid] = s;
     }
   }
@@ -774,8 +782,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
 
 // Matmul arithmetic of the feature kernels (gunet_set_matmul_mode) and the GEMM kernel choice
 // (gunet_set_kernel_choice).
-int g_matmul_mode = GUNET_MATMUL_F32;
-int g_kernel_choice = GUNET_KERNELS_AUTO;
+// Process-wide settings, read at launch time by any host thread.
+std::atomic<int> g_matmul_mode{GUNET_MATMUL_F32};
+std::atomic<int> g_kernel_choice{GUNET_KERNELS_AUTO};
 
 inline int mode_pieces(int mode) {
   return mode == GUNET_MATMUL_SPLIT3 ? 3 : mode == GUNET_MATMUL_SPLIT2 ? 2 : mode == GUNET_MATMUL_BF16 ? 1 : 0;
@@ -805,15 +814,29 @@ int launch_gemm_split(const GemmArgs& g, int nt, dim3 grid, uint4* wpack, hipStr
 }
 
 int device_cu_count() {
-  static int n_cus[64] = {};
+  static std::atomic<int> n_cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (n_cus[dev] == 0) {
-    int n = 0;
+  int n = n_cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    n_cus[dev] = n;
+    n_cus[dev].store(n, std::memory_order_relaxed);
   }
-  return n_cus[dev];
+  return n;
+}
+
+// Largest LDS allocation one workgroup may make on the current device (queried once per device);
+// a weight image that does not fit sends the launch to the tiled kernel.
+size_t device_lds_limit() {
+  static std::atomic<int> limit[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64 * 1024;
+  int n = limit[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || n <= 0) n = 64 * 1024;
+    limit[dev].store(n, std::memory_order_relaxed);
+  }
+  return std::min(static_cast<size_t>(n), kResMaxLds);
 }
 
 // The weights-resident kernels take launches whose operand segments are whole K tiles, with
@@ -846,7 +869,7 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   } else if ((nt != 3 && nt != 4) || (kt != 4 && kt != 8)) {
     return false;
   }
-  if (resident_lds_bytes(nt, kt, bf16) > kResMaxLds) return false;
+  if (resident_lds_bytes(nt, kt, bf16) > device_lds_limit()) return false;
   for (int s = 0; s < g.n_seg; ++s)   // 32-bit byte offsets into every operand segment and the output
     if (batch * g.n_rows * g.seg[s].lda * 4 >= (int64_t{1} << 32)) return false;
   if (batch * (g.out_rows ? g.out_rows : g.n_rows) * g.ldo * 4 >= (int64_t{1} << 32)) return false;
@@ -905,15 +928,16 @@ int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack
 
 template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
 int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
-  static bool raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
+  static std::atomic<bool> raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
   const size_t lds = resident_lds_bytes(NT, NKT, BF16);
   int dev = 0;
   GUNET_HIP_TRY(hipGetDevice(&dev));
   GUNET_REQUIRE(dev >= 0 && dev < 64, "launch_gemm: device index %d", dev);
-  if (!raised[dev]) {
+  if (!raised[dev].load(std::memory_order_acquire)) {   // two threads may both raise it: harmless
     GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResMaxLds)));
-    raised[dev] = true;
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(device_lds_limit())));
+    raised[dev].store(true, std::memory_order_release);
   }
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
@@ -1044,6 +1068,7 @@ size_t gunet_dense_workspace_bytes(int32_t k, int32_t n_out) {
 int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float* kernel,
                             const float* bias, int32_t n_out, int32_t activation, float* out,
                             void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(rows >= 0 && k > 0 && n_out > 0, "dense_forward: bad shape");
   GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU,

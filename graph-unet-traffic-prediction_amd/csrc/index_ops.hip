@@ -599,6 +599,7 @@ int gunet_version(void) { return 1; }
 int gunet_quadrant_partition(const int32_t* edge_index, const int64_t* direction, int64_t n_edges,
                              int32_t* const out_edges[4], int64_t counts_host[4],
                              gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(counts_host != nullptr && out_edges != nullptr, "quadrant_partition: null output");
   GUNET_REQUIRE(n_edges >= 0 && n_edges < INT32_MAX, "quadrant_partition: bad n_edges");
@@ -622,6 +623,7 @@ int gunet_quadrant_partition(const int32_t* edge_index, const int64_t* direction
 
 int gunet_csr_build(const int32_t* edge_index, int64_t n_edges, int32_t n_nodes, int32_t* rowptr,
                     int32_t* perm, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_edges >= 0 && n_edges < INT32_MAX && n_nodes >= 0, "csr_build: bad sizes");
   GUNET_REQUIRE(rowptr != nullptr && (n_edges == 0 || (edge_index != nullptr && perm != nullptr)),
                 "csr_build: null pointer");
@@ -630,6 +632,7 @@ int gunet_csr_build(const int32_t* edge_index, int64_t n_edges, int32_t n_nodes,
 
 int gunet_csr_from_keys(const int32_t* keys, int64_t n, int32_t n_segments, int32_t* rowptr,
                         int32_t* perm, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n >= 0 && n < INT32_MAX && n_segments >= 0, "csr_from_keys: bad sizes");
   GUNET_REQUIRE(rowptr != nullptr && (n == 0 || (keys != nullptr && perm != nullptr)),
                 "csr_from_keys: null pointer");
@@ -638,6 +641,7 @@ int gunet_csr_from_keys(const int32_t* keys, int64_t n, int32_t n_segments, int3
 
 int gunet_cluster_ids(const int64_t* node_loc, int64_t n_nodes, int32_t* cluster,
                       int64_t* pooled_loc, int64_t* n_pooled_host, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(n_pooled_host != nullptr, "cluster_ids: n_pooled_host is null");
   GUNET_REQUIRE(n_nodes >= 0 && n_nodes < INT32_MAX, "cluster_ids: bad n_nodes");
   GUNET_REQUIRE(n_nodes == 0 || (node_loc != nullptr && cluster != nullptr),
@@ -648,6 +652,7 @@ int gunet_cluster_ids(const int64_t* node_loc, int64_t n_nodes, int32_t* cluster
 int gunet_pool_edges(const int32_t* edge_index, int64_t n_edges, const int32_t* cluster,
                      int64_t n_pre, int32_t* new_edges, int32_t* dup_map, int64_t* n_new_host,
                      gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(n_new_host != nullptr, "pool_edges: n_new_host is null");
   *n_new_host = 0;
@@ -693,6 +698,7 @@ int gunet_pool_edges(const int32_t* edge_index, int64_t n_edges, const int32_t* 
 int gunet_upsample_edges(const int64_t* coarse_loc, int64_t n_coarse, const int64_t* fine_loc,
                          int64_t n_fine, int32_t* parent, int32_t* const out_edges[4],
                          int64_t counts_host[4], gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(counts_host != nullptr && out_edges != nullptr, "upsample_edges: null output");
   for (int q = 0; q < 4; ++q) counts_host[q] = 0;
@@ -722,6 +728,7 @@ int gunet_upsample_edges(const int64_t* coarse_loc, int64_t n_coarse, const int6
 
 int gunet_in_edge_table(const gunet_quadgraph* graph, int32_t* table, int32_t* max_in_degree_host,
                         gunet_stream_t stream_) {
+  StreamDeviceGuard device_guard(as_stream(stream_));
   hipStream_t stream = as_stream(stream_);
   GUNET_REQUIRE(graph && max_in_degree_host, "in_edge_table: null argument");
   *max_in_degree_host = 0;

@@ -359,6 +359,7 @@ extern "C" {
 
 int gunet_plan_create(const int64_t* node_loc, int64_t n_nodes, const int32_t* const edge_index[4],
                       const int64_t n_edges[4], int32_t depth, gunet_plan** plan_out, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(plan_out != nullptr, "plan_create: plan_out is null");
   *plan_out = nullptr;
   GUNET_REQUIRE(depth >= 0 && depth <= GUNET_MAX_DEPTH, "plan_create: depth %d outside 0..%d", depth, GUNET_MAX_DEPTH);
@@ -415,6 +416,54 @@ int gunet_plan_upsampling(const gunet_plan* plan, int32_t level, gunet_quadgraph
   return GUNET_OK;
 }
 
+int gunet_plan_pool_features_f32(const gunet_plan* plan, int32_t level, int32_t batch, const float* x, int32_t width,
+                                 const float* const edges[4], int32_t edge_width, float* x_out,
+                                 float* const edges_out[4], gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
+  GUNET_REQUIRE(plan != nullptr, "plan_pool_features: null plan");
+  GUNET_REQUIRE(level >= 0 && level < plan->depth, "plan_pool_features: level %d outside 0..%d", level, plan->depth - 1);
+  GUNET_REQUIRE(batch > 0 && width >= 0 && edge_width >= 0, "plan_pool_features: bad batch or width");
+  int dev = 0;
+  GUNET_HIP_TRY(hipGetDevice(&dev));
+  GUNET_REQUIRE(dev == plan->device, "plan_pool_features: the plan lives on device %d, the current device is %d",
+                plan->device, dev);
+  const gunet_plan::Level& L = plan->levels[level];
+  const gunet_plan::Level& C = plan->levels[level + 1];
+  const gunet_plan::Pool& pool = plan->pools[level];
+  const float* src[5];
+  float* dst[5];
+  const int32_t* rowptr[5];
+  const int32_t* perm[5];
+  int64_t n_src[5], n_seg[5];
+  int widths[5];
+  int n = 0;
+  if (x != nullptr || x_out != nullptr) {
+    GUNET_REQUIRE(x && x_out && width > 0, "plan_pool_features: x, x_out and width go together");
+    src[n] = x;
+    dst[n] = x_out;
+    rowptr[n] = pool.cluster_rowptr;
+    perm[n] = pool.cluster_perm;
+    n_src[n] = L.n_nodes;
+    n_seg[n] = C.n_nodes;
+    widths[n++] = width;
+  }
+  if (edges != nullptr || edges_out != nullptr) {
+    GUNET_REQUIRE(edges && edges_out && edge_width > 0, "plan_pool_features: edges, edges_out and edge_width go together");
+    for (int q = 0; q < 4; ++q) {
+      if (C.n_edges[q] == 0) continue;
+      GUNET_REQUIRE(edges[q] && edges_out[q], "plan_pool_features: null edge tensor %d", q);
+      src[n] = edges[q];
+      dst[n] = edges_out[q];
+      rowptr[n] = pool.dup_rowptr[q];
+      perm[n] = pool.dup_perm[q];
+      n_src[n] = L.n_edges[q];
+      n_seg[n] = C.n_edges[q];
+      widths[n++] = edge_width;
+    }
+  }
+  return pool_max_multi(n, src, n_src, widths, rowptr, perm, n_seg, dst, batch, as_stream(stream));
+}
+
 size_t gunet_unet_workspace_bytes(const gunet_plan* plan, const gunet_unet_weights* weights, int32_t batch) {
   if (plan == nullptr || weights == nullptr || batch <= 0) return 0;
   ModelBuffers mb;
@@ -427,6 +476,7 @@ int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int
                            const float* const edges[4], const float* global_in, int32_t activation,
                            int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
                            void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   return unet_forward(P, w, batch, x, edges, global_in, activation, out_activation, out, edges_out, global_out,
                       workspace, workspace_bytes, as_stream(stream));
 }
@@ -435,6 +485,7 @@ int gunet_unet_forward_static_f32(const gunet_plan* P, const gunet_unet_weights*
                                   const float* const edges[4], const float* global_in, int32_t activation,
                                   int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
                                   gunet_stream_t stream) {
+  StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(P && w, "unet_forward_static: null plan or weights");
   GUNET_REQUIRE(batch > 0, "unet_forward_static: batch %d", batch);
   ModelBuffers mb;

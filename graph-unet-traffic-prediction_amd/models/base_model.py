@@ -1,11 +1,15 @@
 """Caller of the Graph U-Net (reference models/base_model.py:259-331, inference part): the
 street-map CNN, the edge features gathered from it, the per-sample inputs and the final clamp."""
 import ctypes as C
+from collections import OrderedDict
 
 import torch
 
 from .. import _lib, plan as _plan
 from .._lib import call, ptr, current_stream
+
+
+_CITY_LIMIT = 8      # (city, batch) entries of street encodings / edge features kept per model
 
 
 class GraphBaseModel:
@@ -19,7 +23,7 @@ class GraphBaseModel:
     def __init__(self):
         self.cnn1_kernel = None      # [3, 3, 1, 32]  (reference :263)
         self.cnn2_kernel = None      # [3, 3, 32, 8]  (reference :264)
-        self._city = {}
+        self._city = OrderedDict()   # least recently used first; at most _CITY_LIMIT entries
 
     def load_frontend_weights(self, flat, device='cuda'):
         device = torch.device(device)
@@ -79,10 +83,13 @@ class GraphBaseModel:
 
     def _city_features(self, x, batch):
         g = x['graph']
-        key = (x['image']['street_map'].data_ptr(), g['node_loc'].data_ptr(),
-               tuple(e.data_ptr() for e in g['edge_index']), self.cnn1_kernel.data_ptr(), batch)
+        tk = _plan._tensor_key
+        key = (tk(x['image']['street_map']), tk(g['node_loc']), tuple(tk(e) for e in g['edge_index']),
+               tk(self.cnn1_kernel), tk(self.cnn2_kernel), batch)
         hit = self._city.get(key)
-        if hit is None:
+        if hit is not None:
+            self._city.move_to_end(key)
+        else:
             enc = self.forward_street_encoding(x)
             edges = [self.compute_edge_features(enc, e) for e in g['edge_index']]      # :294-298
             if batch is not None:
@@ -90,6 +97,8 @@ class GraphBaseModel:
             # keep the keyed tensors alive so their addresses cannot be reused by another city
             hit = (enc, edges, (x['image']['street_map'], g['node_loc'], list(g['edge_index'])))
             self._city[key] = hit
+            while len(self._city) > _CITY_LIMIT:
+                self._city.popitem(last=False)
         return hit[0], hit[1]
 
     def _call(self, x, training=False):

@@ -94,12 +94,14 @@ class GraphUNet(GraphBaseModel):
                 out.update(layer.named_weights(prefix))
         return out
 
-    def predict(self, x, graph, training=False):
+    def predict(self, x, graph, training=False, out=None):
         """max(GraphUNet(x, graph), 0): what GraphBaseModel._call returns for the forward
-        (reference models/base_model.py:314,325); the clamp is fused into the output GEMM."""
+        (reference models/base_model.py:314,325); the clamp is fused into the output GEMM.
+        out (one-call forward only): a contiguous float32 tensor of the result's shape to write
+        into, e.g. this batch's slice of a buffer that is gathered afterwards."""
         if self.out_model.activation not in (None, 'linear', 'relu'):
             raise NotImplementedError('predict() needs a linear or relu output activation')
-        return self.call(x, graph, training=training, _out_activation='relu')[0]
+        return self.call(x, graph, training=training, _out_activation='relu', _out=out)[0]
 
     # -- whole forward as one library call ---------------------------------------
     def _native_ok(self):
@@ -165,7 +167,7 @@ class GraphUNet(GraphBaseModel):
         self._native_widths = (fe, gw)
         return s
 
-    def _call_native(self, x, graph, out_activation):
+    def _call_native(self, x, graph, out_activation, out=None):
         x = _as_f32(x, 'x')
         single = x.dim() == 2
         xb = x.unsqueeze(0) if single else x
@@ -193,7 +195,14 @@ class GraphUNet(GraphBaseModel):
             feats.append(eb)
         ws = self._native_weights(c_in, feats[0].shape[2], glob.shape[1], dev)
         u_last, g_last = self._native_widths
-        out = torch.empty((batch, n, self.out_model.units), dtype=torch.float32, device=dev)
+        shape = (batch, n, self.out_model.units)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
+        else:
+            if (out.dtype != torch.float32 or out.device != dev or not out.is_contiguous()
+                    or tuple(out.shape) != (shape[1:] if single else shape)):
+                raise ValueError(f'out must be a contiguous float32 tensor of shape {shape[1:] if single else shape} on {dev}')
+            out = out.unsqueeze(0) if single else out
         edges_out = [torch.empty((batch, up.n_edges[0][q], u_last), dtype=torch.float32, device=dev) for q in range(4)]
         global_out = torch.empty((batch, g_last), dtype=torch.float32, device=dev)
         nbytes = int(_lib.lib.gunet_unet_workspace_bytes(up.handle, C.byref(ws), batch))
@@ -218,10 +227,12 @@ class GraphUNet(GraphBaseModel):
         graph['global'] = global_out
         return out, graph
 
-    def call(self, x, graph, training=False, _out_activation=Ellipsis):
+    def call(self, x, graph, training=False, _out_activation=Ellipsis, _out=None):
         if self._native_ok():
             act = self.out_model._act if _out_activation is Ellipsis else _activation_code(_out_activation)
-            return self._call_native(x, graph, act)
+            return self._call_native(x, graph, act, _out)
+        if _out is not None:
+            raise NotImplementedError('out= needs the one-call forward (native_forward)')
         skip_graphs = []
         skips = []
         x = self.in_layer(x)

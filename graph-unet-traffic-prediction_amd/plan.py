@@ -2,7 +2,9 @@
 
 Everything here depends only on the static city graph, so it is built once (on
 the GPU, through the C ABI) and cached by the identity of the index tensors it
-was built from.  The reference recomputes all of it inside every forward
+was built from (storage address, row count and torch's in-place version
+counter: editing an index tensor in place gives a new key and a fresh plan).
+The reference recomputes all of it inside every forward
 (layers/hybrid_gnn.py:410-447, :267-280, :336-357; tf.unique and boolean masks).
 
   QuadGraph     four reference-ordered edge lists + receiver-sorted CSR per list
@@ -31,6 +33,20 @@ def _remember(cache, key, value):
     while len(cache) > _CACHE_LIMIT:
         cache.popitem(last=False)
     return value
+
+
+def _lookup(cache, key):
+    """Cache hit, marked as the most recently used entry (eviction takes the least recently used)."""
+    hit = cache.get(key)
+    if hit is not None:
+        cache.move_to_end(key)
+    return hit
+
+
+def _tensor_key(t):
+    """Identity of an index tensor's contents as far as torch can tell: its storage address, row
+    count and in-place version counter (bumped by every in-place edit through torch)."""
+    return (t.data_ptr(), int(t.shape[0]), int(t._version))
 
 
 def clear_caches():
@@ -115,13 +131,13 @@ class QuadGraph:
 
 
 def _edge_key(edge_index):
-    return tuple((e.data_ptr(), int(e.shape[0])) for e in edge_index)
+    return tuple(_tensor_key(e) for e in edge_index)
 
 
 def get_quadgraph(edge_index, n_nodes):
     """Cached QuadGraph for a list of 4 edge tensors (keyed by their storage)."""
     key = (_edge_key(edge_index), int(n_nodes))
-    hit = _quad_cache.get(key)
+    hit = _lookup(_quad_cache, key)
     if hit is not None:
         return hit
     plan = QuadGraph(edge_index, n_nodes)
@@ -168,8 +184,8 @@ class PoolPlan:
 
 
 def get_pool_plan(node_loc, edge_index):
-    key = (node_loc.data_ptr(), int(node_loc.shape[0]), _edge_key(edge_index))
-    hit = _pool_cache.get(key)
+    key = (_tensor_key(node_loc), _edge_key(edge_index))
+    hit = _lookup(_pool_cache, key)
     if hit is not None:
         return hit
     plan = PoolPlan(node_loc, edge_index)
@@ -201,9 +217,8 @@ class UpsamplePlan:
 
 
 def get_upsample_plan(coarse_loc, fine_loc):
-    key = (coarse_loc.data_ptr(), int(coarse_loc.shape[0]), fine_loc.data_ptr(),
-           int(fine_loc.shape[0]))
-    hit = _up_cache.get(key)
+    key = (_tensor_key(coarse_loc), _tensor_key(fine_loc))
+    hit = _lookup(_up_cache, key)
     if hit is not None:
         return hit
     plan = UpsamplePlan(coarse_loc, fine_loc)
@@ -295,8 +310,8 @@ _unet_cache = OrderedDict()
 
 
 def get_unet_plan(node_loc, edge_index, depth):
-    key = (node_loc.data_ptr(), int(node_loc.shape[0]), _edge_key(edge_index), int(depth))
-    hit = _unet_cache.get(key)
+    key = (_tensor_key(node_loc), _edge_key(edge_index), int(depth))
+    hit = _lookup(_unet_cache, key)
     if hit is not None:
         return hit
     plan = UNetPlan(node_loc, edge_index, depth)
@@ -310,9 +325,9 @@ _scopes = []
 
 
 class WorkspaceScope:
-    """Scratch buffers of their own for everything run inside `with scope:`.  The shared per-device
-    buffers below are replaced by a larger allocation when a later call needs more, which would
-    pull the memory from under a captured HIP graph; a capture runs inside a scope and keeps it."""
+    """Scratch buffers of their own for everything run inside `with scope:`.  The shared buffers
+    below are replaced by a larger allocation when a later call needs more, which would pull the
+    memory from under a captured HIP graph; a capture runs inside a scope and keeps it."""
 
     def __init__(self):
         self.layer, self.model = {}, {}
@@ -327,7 +342,9 @@ class WorkspaceScope:
 
 
 def _grown(table, nbytes, device, slack):
-    key = (device.type, device.index)
+    # one buffer per (device, stream): kernels of one stream use it in order, two streams never
+    # share one, so forwards issued on different streams of a device cannot race on scratch
+    key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
     buf = table.get(key)
     if buf is None or buf.numel() < nbytes:
         table[key] = None            # let go of the old buffer before asking for the new one
@@ -337,11 +354,23 @@ def _grown(table, nbytes, device, slack):
 
 
 def workspace(nbytes, device):
-    """A per-device scratch buffer that only grows; kernels on one stream reuse it in order."""
+    """Scratch buffer of the current stream of `device`; it only grows and is reused in stream order."""
     return _grown(_scopes[-1].layer if _scopes else _workspaces, nbytes, device, 1.25)
 
 
 def model_workspace(nbytes, device):
-    """Per-device buffer of the whole-model entry point (all intermediates of one forward, skip
-    tensors included); grows to the largest request and is reused in stream order."""
+    """Buffer of the whole-model entry point (all intermediates of one forward, skip tensors
+    included) for the current stream of `device`; grows to the largest request."""
     return _grown(_scopes[-1].model if _scopes else _model_workspaces, nbytes, device, 1.0)
+
+
+def model_workspace_of(device):
+    """The largest whole-model buffer held for `device` (any stream), or None."""
+    bufs = [b for k, b in _model_workspaces.items() if k[:2] == (device.type, device.index) and b is not None]
+    return max(bufs, key=lambda b: b.numel()) if bufs else None
+
+
+def release_workspaces():
+    """Drop every shared scratch buffer (they are re-allocated on demand)."""
+    _workspaces.clear()
+    _model_workspaces.clear()

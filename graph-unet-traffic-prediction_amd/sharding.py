@@ -26,28 +26,64 @@ def shard_by_city(sample_cities, world_size, rank):
     return order[lo:hi]
 
 
-def gather_rows(local, dst=0, group=None):
+def city_groups(sample_ids, sample_cities):
+    """[(city, [sample ids])] for a rank's (city-ordered) sample ids: runs of equal city, which a
+    rank forwards as one batch over that city's plan."""
+    groups = []
+    for i in sample_ids:
+        c = sample_cities[i]
+        if groups and groups[-1][0] == c:
+            groups[-1][1].append(i)
+        else:
+            groups.append((c, [i]))
+    return groups
+
+
+def row_counts(n_local, device, group=None):
+    """Row count of every rank's block (a list of ints): one small all-reduce.  The counts of a
+    fixed sharding never change, so a caller gathers them once and passes them to gather_rows."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [int(n_local)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    counts[rank] = int(n_local)
+    dist.all_reduce(counts, group=group)
+    return [int(c) for c in counts.tolist()]
+
+
+def gather_rows(local, dst=0, group=None, counts=None, out=None):
     """Gather variable-length [n_i, ...] tensors on rank dst (concatenated in rank order; None on
-    the other ranks).  Row counts may differ between ranks (cities differ in node count)."""
+    the other ranks).  Row counts may differ between ranks (cities differ in node count).
+    counts: row_counts() of this sharding (fetched when absent); out: [sum(counts), ...] buffer on
+    rank dst to receive into (allocated when absent).  Point-to-point: every sender writes its
+    block straight into its slice of the collector's buffer, all receives posted as one batch so
+    that they run on the senders' own links side by side."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    counts = torch.zeros(world, dtype=torch.int64, device=local.device)
-    counts[rank] = local.shape[0]
-    dist.all_reduce(counts, group=group)
-    counts = counts.tolist()
+    if counts is None:
+        counts = row_counts(local.shape[0], local.device, group)
     local = local.contiguous()
     if rank == dst:
-        parts = [local if r == rank else
-                 torch.empty((counts[r],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-                 for r in range(world)]
-        reqs = [dist.irecv(parts[r], src=r, group=group) for r in range(world) if r != rank and counts[r] > 0]
-        for req in reqs:
-            req.wait()
-        return torch.cat(parts, dim=0)
+        total = sum(counts)
+        if out is None:
+            out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        offs = [sum(counts[:r]) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r] + counts[r]], _global_rank(r, group), group)
+               for r in range(world) if r != rank and counts[r] > 0]
+        out[offs[rank]:offs[rank] + counts[rank]].copy_(local)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
     if counts[rank] > 0:
-        dist.isend(local, dst=dst, group=group).wait()
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, _global_rank(dst, group), group)]):
+            req.wait()
     return None
+
+
+def _global_rank(r, group):
+    return r if group is None else dist.get_global_rank(group, r)
 
 
 def gather_equal(local, dst=0, group=None, out=None):

@@ -264,6 +264,16 @@ int gunet_plan_pooling(const gunet_plan* plan, int32_t level, const int32_t** cl
 int gunet_plan_upsampling(const gunet_plan* plan, int32_t level, gunet_quadgraph* graph_out,
                           const int32_t** parent_out);
 
+/* layers/hybrid_gnn.py:427 and :401 (graph_pooling_2x2, feature part) for pooling `level` -> level + 1
+ * of a plan, as one launch: x_out [B, n_{l+1}, width] = unsorted_segment_max(x [B, n_l, width],
+ * cluster) and, per quadrant, edges_out[q] [B, E_{l+1,q}, edge_width] = the maximum of
+ * edges[q] [B, E_lq, edge_width] over the fine edges that map to each pooled edge (self-loops
+ * dropped).  Either half may be left out (x = x_out = NULL, or edges = edges_out = NULL).
+ * Asynchronous on `stream`, allocates nothing.  Maxima are exact: bit-identical to the reference. */
+int gunet_plan_pool_features_f32(const gunet_plan* plan, int32_t level, int32_t batch, const float* x,
+                                 int32_t width, const float* const edges[4], int32_t edge_width,
+                                 float* x_out, float* const edges_out[4], gunet_stream_t stream);
+
 /* Parameters of GraphUNet (models/graph_unet.py:21-59) in the checkpoint's layout.  The in_layer's
  * width is down[0].c_in; every later width follows from the layers' own fields, and the forward
  * checks that they chain as the model wires them. */

@@ -36,6 +36,30 @@ def rel_err(got, want):
     return float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-30))
 
 
+def elementwise_err(got, want, floor=0.1):
+    """Elementwise relative error with an absolute floor: max over entries of
+    |got - want| / max(|want|, floor * max|want|).  An entry of a float32 matrix product carries an
+    absolute rounding error set by the size of the terms that were summed, not by its own size, so
+    entries far below the tensor's scale cannot be held to a relative bound; `floor` says from which
+    fraction of the scale downwards the bound turns absolute."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if want.size == 0:
+        return 0.0
+    top = max(float(np.max(np.abs(want))), 1e-30)
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), floor * top)))
+
+
+def assert_close(got, want, tol=1e-5, what=''):
+    """The two float32 parity gates: normwise max|d| / max|want| <= tol, and elementwise
+    |d| <= tol * max(|want|, 0.1 max|want|) (every entry within a decade of the scale holds `tol`
+    relative to itself, smaller ones tol/10 of the scale absolutely)."""
+    n, e = rel_err(got, want), elementwise_err(got, want)
+    assert n <= tol and e <= tol, f'{what}: normwise {n:.2e}, elementwise {e:.2e} (gate {tol:.0e})'
+    return n, e
+
+
 @pytest.fixture(scope='session')
 def oracle():
     import gunet_oracle

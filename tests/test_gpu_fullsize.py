@@ -1,0 +1,202 @@
+"""The benchmark configurations at their full sizes on the GPU, against the CPU oracle.
+
+  cfg 2  whole model, 495x436 road graph, batch 8: three distinct samples against the float32
+         oracle (normwise and elementwise gates), and against the same forward in float64 -- the HIP
+         result must sit as close to the exact value as the float32 oracle does;
+  cfg 3  pooling chain at batch 32: node features [32, N, 128] and the four edge-feature sets through
+         levels 0 -> 1 -> 2 -> 3, bit-exact per sample; then the three upsampling GN layers 3 -> 0 at
+         batch 32 against the oracle;
+  cfg 4  the six 495x436 cities, 64 samples: one sample per city against the oracle, and the
+         sharding orders of 1 and 8 ranks bit-identical sample by sample;
+  cfg 5  the whole 256-wide model on the dense grid against the oracle (one sample).
+
+Tolerances are written where they are used: index and max-pooled tensors bit-exact, float32
+features 1e-5 (conftest.assert_close: normwise and elementwise)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, elementwise_err, rel_err
+from gpu_helpers import copy_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+H, W_ = 495, 436
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import gunet_amd
+    return gunet_amd
+
+
+def _model(amd, weights, **kw):
+    units = kw.pop('units', 32)
+    m = amd.GraphUNet(units, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn', use_bias=True,
+                      use_global=True, output_activation=None, **kw)
+    return m.load_weights(weights, 'cuda')
+
+
+def _city(amd, density, seed, dense=False):
+    from gunet_amd import synthetic
+    node_loc, ei, d = synthetic.dense_graph(H, W_) if dense else synthetic.road_graph(H, W_, density, seed)
+    quads = amd.data_utils.sample_quadrant_subgraphs(to_dev(ei, torch.int32), to_dev(d, torch.int64))
+    return node_loc, quads, [q.cpu().numpy() for q in quads]
+
+
+def _samples(node_loc, quads_np, enc, ids):
+    from gunet_amd import synthetic
+    out = []
+    for sid in ids:
+        sn, te, wd = synthetic.sample_inputs(node_loc.shape[0], 1000 + sid, time_idx=12 * sid, weekday=sid)
+        out.append(synthetic.assemble_model_inputs(sn, enc, quads_np, te, wd))
+    return out
+
+
+def _batch_graph(quads, node_loc_dev, edges_np, globs, batch):
+    return {'edge_index': list(quads), 'node_loc': node_loc_dev,
+            'edges': [to_dev(e).unsqueeze(0).repeat(batch, 1, 1).contiguous() for e in edges_np],
+            'global': to_dev(np.concatenate(globs, axis=0))}
+
+
+def test_cfg2_full_model_batch8(amd, oracle):
+    from gunet_amd import synthetic
+    node_loc, quads, quads_np = _city(amd, 0.45, 0)
+    n = node_loc.shape[0]
+    assert n == 96493 and sum(q.shape[0] for q in quads_np) == 524102
+    weights = synthetic.random_weights(synthetic.graph_unet_shapes_for(32), 1)
+    model = _model(amd, weights)
+    enc = synthetic.street_encoding(n, 5)
+    samples = _samples(node_loc, quads_np, enc, range(8))
+    g = _batch_graph(quads, to_dev(node_loc, torch.int64), samples[0][1], [s[2] for s in samples], 8)
+    y = model.predict(to_dev(np.stack([s[0] for s in samples])), g).cpu().numpy()
+    assert y.shape == (8, n, 96) and (y >= 0).all()
+    for b in (0, 3, 7):
+        x, edges, glob = samples[b]
+        graph = {'edge_index': list(quads_np), 'edges': list(edges), 'node_loc': node_loc, 'global': glob}
+        want, _ = oracle.predict(x, copy_graph(graph), weights)
+        assert_close(y[b], want, TOL, f'sample {b}')
+    # distance to the exact result: the same forward in float64 (sample 3 from above)
+    w64 = {k: np.asarray(v, np.float64) for k, v in weights.items()}
+    g64 = {'edge_index': list(quads_np), 'edges': [e.astype(np.float64) for e in edges], 'node_loc': node_loc,
+           'global': samples[3][2].astype(np.float64)}
+    x3, edges3, glob3 = samples[3]
+    g64['edges'] = [e.astype(np.float64) for e in edges3]
+    exact, _ = oracle.predict(x3.astype(np.float64), g64, w64)
+    g32 = {'edge_index': list(quads_np), 'edges': list(edges3), 'node_loc': node_loc, 'global': glob3}
+    want3, _ = oracle.predict(x3, g32, weights)
+    hip, ora = rel_err(y[3], exact), rel_err(want3, exact)
+    assert hip <= TOL and hip <= 2 * ora + 1e-7, (hip, ora)
+    # elementwise with the floor three decades below the scale: both float32 computations carry the
+    # same kind of absolute error there; the HIP one must not be the worse by more than 2x
+    hip_e, ora_e = elementwise_err(y[3], exact, 1e-3), elementwise_err(want3, exact, 1e-3)
+    assert hip_e <= 2 * ora_e + 1e-6, (hip_e, ora_e)
+
+
+def test_cfg3_pool_chain_batch32_then_upsampling_layers(amd, oracle):
+    from gunet_amd import _lib, plan, synthetic
+    from gunet_amd.layers.hybrid_gnn import GeoQuadrantGCN
+    node_loc, quads, quads_np = _city(amd, 0.45, 0)
+    n, B, U, u = node_loc.shape[0], 32, 128, 32
+    loc_dev = to_dev(node_loc, torch.int64)
+    up = plan.UNetPlan(loc_dev, quads, 3)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    x = [torch.rand((B, n, U), generator=gen, device='cuda') - 0.3]
+    e = [[torch.rand((B, up.n_edges[0][q], u), generator=gen, device='cuda') - 0.3 for q in range(4)]]
+    for l in range(3):
+        x.append(torch.empty((B, up.n_nodes[l + 1], U), device='cuda'))
+        e.append([torch.empty((B, up.n_edges[l + 1][q], u), device='cuda') for q in range(4)])
+        src, dst = _lib.ptr4(e[l]), _lib.ptr4(e[l + 1])
+        _lib.call('gunet_plan_pool_features_f32', up.handle, l, B, _lib.ptr(x[l]), U, C.byref(src), u,
+                  _lib.ptr(x[l + 1]), C.byref(dst), _lib.current_stream(x[0].device))
+    # the oracle pools all 32 samples at once: segment maxima act on every column by itself, so
+    # the samples ride side by side as column blocks of one wide feature matrix
+    wide = lambda t: t.permute(1, 0, 2).reshape(t.shape[1], -1).cpu().numpy()
+    xc = wide(x[0])
+    graph = {'edge_index': list(quads_np), 'edges': [wide(t) for t in e[0]], 'node_loc': node_loc, 'global': None}
+    locs = [node_loc]
+    for l in range(3):
+        xc, graph = oracle.graph_pooling_2x2(xc, graph)
+        locs.append(graph['node_loc'])
+        lv = up.level(l + 1)
+        assert np.array_equal(lv['node_loc'].cpu().numpy(), graph['node_loc'])                 # bit-exact index side
+        assert np.array_equal(wide(x[l + 1]), xc), f'node features, level {l + 1}'              # bit-exact maxima, all samples
+        for q in range(4):
+            assert np.array_equal(lv['edge_index'][q].cpu().numpy(), graph['edge_index'][q])
+            assert np.array_equal(wide(e[l + 1][q]), graph['edges'][q]), f'edge features {q}, level {l + 1}'
+    # way up: the GN layer of GraphUpsampling2x2 at every level, batch 32, fed with the pooled features
+    for l in (2, 1, 0):
+        g_w, t_w = 128, (113 if l == 0 else 128)
+        prefix = f'upsampling_layers/{2 - l}/upsampling/gcn'
+        wts = synthetic.random_weights(synthetic.gn_layer_shapes(prefix, U, 2, g_w + t_w, U), 20 + l)
+        layer = GeoQuadrantGCN(U, activation='relu', use_bias=True, use_global=True)
+        layer.load_weights(wts, prefix, 'cuda')
+        glob = torch.rand((B, g_w + t_w), generator=gen, device='cuda')
+        upl = plan.get_upsample_plan(up.level(l + 1)['node_loc'], up.level(l)['node_loc'])
+        got, got_g = layer._upsample_forward(x[l + 1], glob, upl)
+        assert got.shape == (B, up.n_nodes[l], U)
+        for b in (0, 17, 31):
+            cg = {'node_loc': locs[l + 1], 'global': glob[b:b + 1, :g_w].cpu().numpy(), 'edge_index': None, 'edges': None}
+            tg = {'node_loc': locs[l], 'global': glob[b:b + 1, g_w:].cpu().numpy(), 'edge_index': None, 'edges': None}
+            want, want_g = oracle.graph_upsampling_graph(x[l + 1][b].cpu().numpy(), cg, tg, wts, prefix[:-4])
+            assert_close(got[b].cpu().numpy(), want, TOL, f'upsampling level {l}, sample {b}')
+            assert_close(got_g[b:b + 1].cpu().numpy(), want_g['global'], TOL, f'upsampling global level {l}, sample {b}')
+
+
+def test_cfg4_six_cities_64_samples_sharding_orders(amd, oracle):
+    from gunet_amd import sharding, synthetic
+    seeds, dens = (10, 11, 12, 13, 14, 15), (0.25, 0.30, 0.35, 0.40, 0.50, 0.60)
+    weights = synthetic.random_weights(synthetic.graph_unet_shapes_for(32), 1)
+    model = _model(amd, weights)
+    cities = []
+    for c in range(6):
+        node_loc, quads, quads_np = _city(amd, dens[c], seeds[c])
+        cities.append({'loc': node_loc, 'quads': quads, 'quads_np': quads_np, 'loc_dev': to_dev(node_loc, torch.int64),
+                       'enc': synthetic.street_encoding(node_loc.shape[0], 5 + c)})
+    sample_cities = [i % 6 for i in range(64)]
+
+    def run(world):
+        out = {}
+        for rank in range(world):
+            mine = sharding.shard_by_city(sample_cities, world, rank)
+            for c, ids in sharding.city_groups(mine, sample_cities):
+                d = cities[c]
+                samples = _samples(d['loc'], d['quads_np'], d['enc'], ids)
+                g = _batch_graph(d['quads'], d['loc_dev'], samples[0][1], [s[2] for s in samples], len(ids))
+                y = model.predict(to_dev(np.stack([s[0] for s in samples])), g)
+                for j, sid in enumerate(ids):
+                    out[sid] = (y[j].clone(), samples[j]) if world == 1 else y[j].clone()
+        return out
+
+    one = run(1)
+    assert sorted(one) == list(range(64))
+    for c in range(6):                      # one sample of every city against the oracle
+        sid = c + 6 * (c % 3)
+        y, (x, edges, glob) = one[sid]
+        d = cities[c]
+        graph = {'edge_index': list(d['quads_np']), 'edges': list(edges), 'node_loc': d['loc'], 'global': glob}
+        want, _ = oracle.predict(x, graph, weights)
+        assert_close(y.cpu().numpy(), want, TOL, f'city {c}, sample {sid}')
+    eight = run(8)                          # other ranks, other batch sizes, other neighbours: same bits
+    for sid in range(64):
+        assert torch.equal(eight[sid], one[sid][0]), sid
+
+
+def test_cfg5_dense_grid_width256_whole_model(amd, oracle):
+    from gunet_amd import synthetic
+    node_loc, quads, quads_np = _city(amd, 1.0, 0, dense=True)
+    n = node_loc.shape[0]
+    assert n == H * W_ and [q.shape[0] for q in quads_np] == [645599] * 4
+    weights = synthetic.random_weights(synthetic.graph_unet_shapes_for(32, min_units=256), 1)
+    model = _model(amd, weights, min_units=256)
+    enc = synthetic.street_encoding(n, 5)
+    (x, edges, glob), = _samples(node_loc, quads_np, enc, [2])
+    g = {'edge_index': list(quads), 'node_loc': to_dev(node_loc, torch.int64), 'edges': [to_dev(e) for e in edges],
+         'global': to_dev(glob)}
+    y = model.predict(to_dev(x), g)
+    graph = {'edge_index': list(quads_np), 'edges': list(edges), 'node_loc': node_loc, 'global': glob}
+    want, _ = oracle.predict(x, graph, weights)
+    assert_close(y.cpu().numpy(), want, TOL, 'dense grid, width 256')
