@@ -9,7 +9,7 @@ tensorflow-gpu==2.6.0 (requirements.txt:8), which is not installable here, and
 the reference ships no tests or golden vectors for this path.  The pins that do
 exist are (1) the variable names/shapes of the shipped checkpoint index
 (tests/golden/ckpt_shapes.json), (2) hand-derived micro known-answers
-(tests/test_oracle_micro.py) and (3) structural invariants of grid graphs.
+(tests/test_oracle.py) and (3) structural invariants of grid graphs.
 
 Every function follows the reference operation order (unfused: four separate
 dense layers, explicit gathers, concat, tile, segment ops) and cites the lines

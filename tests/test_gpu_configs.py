@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
 from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -42,10 +42,10 @@ def test_dense_grid_width256_layer(amd, oracle):
     g = graph_to_dev(graph)
     ei_dev = g['edge_index']
     got_x, got_g = layer(to_dev(x), g)
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     for q in range(4):
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
     # batch of 2 = the single call twice, bit for bit (also a second run of the same kernels)
     gb = graph_to_dev(graph)
     gb['edge_index'] = ei_dev
@@ -87,7 +87,7 @@ def test_six_cities_one_process(amd, oracle):
                 y = model.predict(to_dev(x), g)
                 if world == 1:
                     want, _ = oracle.predict(x, copy_graph(graph), W)
-                    assert rel_err(y.cpu().numpy(), want) <= TOL, i
+                    assert_close(y.cpu().numpy(), want, TOL, str(i))
                     results[i] = y
                 else:
                     assert torch.equal(y, results[i]), (rank, i)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
 from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,7 @@ def test_dense_forward(amd):
             want = np.maximum(want, 0)
         assert got.shape == (rows, n)
         if rows:
-            assert rel_err(got, want) <= TOL, (rows, k, n)
+            assert_close(got, want, TOL, str((rows, k, n)))
 
 
 def test_get_sender_receiver(amd, oracle):
@@ -82,10 +82,10 @@ def test_gn_layer_small(amd, oracle, shape):
     keep = {}
     want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L', keep=keep)
     got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L')
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
     for q in range(4):
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
 
 
 def test_gn_layer_variants(amd, oracle):
@@ -102,17 +102,17 @@ def test_gn_layer_variants(amd, oracle):
     want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
     got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L', with_gt=False)
     assert want_g['global'].shape == (1, 288) and tuple(got_g['global'].shape) == (1, 288)
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
 
     W = _layer_weights(oracle, 'L', 128, 32, 128)
     for act, bias in ((None, True), ('relu', False)):
         want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L', activation=act, use_bias=bias)
         got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L', activation=act, use_bias=bias)
-        assert rel_err(got_x.cpu().numpy(), want_x) <= TOL, (act, bias)
-        assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL, (act, bias)
+        assert_close(got_x.cpu().numpy(), want_x, TOL, str((act, bias)))
+        assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL, str((act, bias)))
         for q in range(4):
-            assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+            assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
 
     got_b, got_gb = _run_layer(amd, oracle, x, graph, W, 'L', batch=3, use_bias=False)
     for b in range(3):                      # every sample of a batch equals the single-sample call, bit for bit
@@ -149,10 +149,10 @@ def test_gn_layer_config1_road_graph(amd, oracle):
     keep = {}
     want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L', keep=keep)
     got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L')
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
     for q in range(4):
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     # run twice: all reductions are ordered, so the result is bitwise reproducible
     again_x, again_g = _run_layer(amd, oracle, x, graph, W, 'L')
     assert torch.equal(again_x, got_x) and torch.equal(again_g['global'], got_g['global'])
@@ -201,11 +201,11 @@ def test_graph_unet_small(amd, oracle, size):
     model = _unet(amd, oracle, W)
     got_y, got_g = model(to_dev(x), graph_to_dev(graph))
     assert tuple(got_y.shape) == want_y.shape
-    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_y.cpu().numpy(), want_y, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     for q in range(4):
         assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), want_g['edge_index'][q])
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
     assert np.array_equal(got_g['node_loc'].cpu().numpy(), want_g['node_loc'])
 
 
@@ -230,8 +230,8 @@ def test_graph_unet_config2_road_graph(amd, oracle):
     got_y = torch.clamp_min(got_y, 0).cpu().numpy()
     for b in range(2):
         want_y, want_g = oracle.predict(xs[b], copy_graph(graphs[b]), W)
-        assert rel_err(got_y[b], want_y) <= TOL, b
-        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
+        assert_close(got_y[b], want_y, TOL, str(b))
+        assert_close(got_g['global'][b:b + 1].cpu().numpy(), want_g['global'], TOL)
 
 
 def test_graph_upsampling_layer(amd, oracle):
@@ -255,8 +255,8 @@ def test_graph_upsampling_layer(amd, oracle):
     up.gcn.load_weights(W, 'U/gcn', 'cuda')
     got_x, got_g = up(to_dev(x), graph_to_dev(coarse), graph_to_dev(fine))
     assert tuple(got_x.shape) == want_x.shape
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     for q in range(4):                                  # the target graph's lists and features come back
         assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), fine['edge_index'][q])
         assert np.array_equal(got_g['edges'][q].cpu().numpy(), fine['edges'][q])
@@ -323,10 +323,10 @@ def test_gn_layer_arbitrary_graph(amd, oracle):
     got_x, got_g = _run_layer(amd, oracle, x, graph, W, 'L')
     qg = amd.plan.get_quadgraph(graph_to_dev(graph)['edge_index'], n)
     assert qg.max_in_degree > 3 and qg.in_table is None
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     for q in range(4):
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
 
 
 def test_in_edge_table(amd, oracle):
@@ -365,8 +365,8 @@ def test_graph_unet_kernel_choices(amd, oracle, choice):
         got_y, got_glob = got_y.cpu().numpy(), got_g['global'].cpu().numpy()
     finally:
         amd.set_kernel_choice('auto')
-    assert rel_err(got_y, want_y) <= TOL
-    assert rel_err(got_glob, want_g['global']) <= TOL
+    assert_close(got_y, want_y, TOL)
+    assert_close(got_glob, want_g['global'], TOL)
 
 
 @pytest.mark.parametrize('k', [104, 100, 124, 116])
@@ -388,7 +388,7 @@ def test_dense_ragged_k_resident(amd, resident_kernels, k):
     got = layer(xd).cpu().numpy()
     want = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0)
     assert np.isfinite(got).all()
-    assert rel_err(got, want) <= TOL
+    assert_close(got, want, TOL)
     amd.set_kernel_choice('tiled')
     tiled = layer(xd).cpu().numpy()
     assert rel_err(got, tiled) <= 1e-6
@@ -414,8 +414,8 @@ def test_gn_layer_fused_aggregation_edge_cases(amd, oracle, resident_kernels):
     assert amd.plan.get_quadgraph(g['edge_index'], n).in_table is not None
     xt = to_dev(x)
     got_x, got_g = layer._forward(xt[:, :128].contiguous(), g, x_skip=xt[:, 128:].contiguous())
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     g2 = graph_to_dev(graph)
     g2['edge_index'] = g['edge_index']
     g2['edges'] = [e.unsqueeze(0).repeat(3, 1, 1) for e in g2['edges']]

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
 from gpu_helpers import to_dev
 
 pytestmark = pytest.mark.gpu
@@ -52,7 +52,7 @@ def test_street_encoding_and_edge_features(amd, oracle):
     model = _model(amd, W)
     x = {'image': {'street_map': to_dev(smap)}, 'graph': {'node_loc': to_dev(node_loc, torch.int64)}}
     got = model.forward_street_encoding(x)
-    assert rel_err(got.cpu().numpy(), want) <= TOL
+    assert_close(got.cpu().numpy(), want, TOL)
     for q in quads:
         feats = model.compute_edge_features(got, to_dev(q, torch.int32))
         assert np.array_equal(feats.cpu().numpy(), oracle.compute_edge_features(got.cpu().numpy(), q))
@@ -80,12 +80,12 @@ def test_model_call(amd, oracle):
                  'time_enc': to_dev(te), 'weekday': to_dev(wd)}
         got = model._call(x_dev)
         assert tuple(got.shape) == (n, 96) and float(got.min()) >= 0
-        assert rel_err(got.cpu().numpy(), wants[b]) <= TOL, b
+        assert_close(got.cpu().numpy(), wants[b], TOL, str(b))
     xb = {'graph': dict(graph_dev, seed_nodes=to_dev(np.stack(seeds))), 'image': image_dev,
           'time_enc': to_dev(np.concatenate(tencs)), 'weekday': to_dev(np.concatenate(wds))}
     got = model._call(xb)
     for b in range(2):
-        assert rel_err(got[b].cpu().numpy(), wants[b]) <= TOL, b
+        assert_close(got[b].cpu().numpy(), wants[b], TOL, str(b))
     with pytest.raises(NotImplementedError):
         model._call(xb, training=True)
 

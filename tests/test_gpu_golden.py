@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, assert_close, rel_err
 from gpu_helpers import to_dev
 
 pytestmark = pytest.mark.gpu
@@ -27,10 +27,10 @@ def test_unet_golden(oracle, name):
     graph = {'edge_index': list(quads), 'edges': [to_dev(z[f'edges_in{q}']) for q in range(4)],
              'node_loc': to_dev(z['node_loc'], torch.int64), 'global': to_dev(z['global'])}
     y, g = model(to_dev(z['x']), graph)
-    assert rel_err(y.cpu().numpy(), z['y']) <= TOL
-    assert rel_err(g['global'].cpu().numpy(), z['global_out']) <= TOL
+    assert_close(y.cpu().numpy(), z['y'], TOL)
+    assert_close(g['global'].cpu().numpy(), z['global_out'], TOL)
     for q in range(4):
-        assert rel_err(g['edges'][q].cpu().numpy(), z[f'edges_out{q}']) <= TOL
+        assert_close(g['edges'][q].cpu().numpy(), z[f'edges_out{q}'], TOL)
     loc, edges = to_dev(z['node_loc'], torch.int64), list(quads)
     for lvl in range(3):
         pp = gunet_amd.plan.get_pool_plan(loc, edges)
@@ -51,7 +51,7 @@ def test_gn_layer_golden(oracle):
              'edges': [to_dev(z[f'edges_in{q}']) for q in range(4)],
              'node_loc': to_dev(z['node_loc'], torch.int64), 'global': to_dev(z['global'])}
     y, g = layer(to_dev(z['x']), graph)
-    assert rel_err(y.cpu().numpy(), z['y']) <= TOL
-    assert rel_err(g['global'].cpu().numpy(), z['global_out']) <= TOL
+    assert_close(y.cpu().numpy(), z['y'], TOL)
+    assert_close(g['global'].cpu().numpy(), z['global_out'], TOL)
     for q in range(4):
-        assert rel_err(g['edges'][q].cpu().numpy(), z[f'edges_out{q}']) <= TOL
+        assert_close(g['edges'][q].cpu().numpy(), z[f'edges_out{q}'], TOL)

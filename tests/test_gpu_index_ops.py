@@ -161,3 +161,30 @@ def test_plan_cache_reuses_structures(amd, oracle):
     a = amd.plan.get_quadgraph(quads, node_loc.shape[0])
     b = amd.plan.get_quadgraph(list(quads), node_loc.shape[0])
     assert a is b
+
+
+def test_pooling_and_collision_hand_derived(amd):
+    """The two hand-worked cases of tests/test_oracle.py through the library (no oracle involved):
+    dedup-then-self-loop removal with the pre-pooling node count in the key, and a cell-id
+    collision on a graph much wider than high, where no fine node gets an upsampling edge."""
+    from gunet_amd.layers.hybrid_gnn import graph_pooling_2x2
+    e0 = torch.tensor([[0, 1], [1, 2], [0, 2], [2, 3], [3, 1], [1, 2]], dtype=torch.int32).cuda()
+    none = torch.zeros((0, 2), dtype=torch.int32).cuda()
+    g = {'node_loc': torch.tensor([[0, 0], [0, 1], [0, 2], [1, 2]], dtype=torch.int64).cuda(),
+         'edge_index': [e0, none, none.clone(), none.clone()],
+         'edges': [torch.tensor([[1.], [5.], [3.], [7.], [2.], [4.]]).cuda()] + [torch.zeros((0, 1)).cuda() for _ in range(3)]}
+    x = torch.tensor([[1., -1.], [0., 3.], [2., 2.], [5., -4.]]).cuda()
+    xp, g = graph_pooling_2x2(x, g)
+    assert xp.cpu().tolist() == [[1., 3.], [5., 2.]]
+    assert g['node_loc'].cpu().tolist() == [[0, 0], [0, 1]]
+    assert g['edge_index'][0].cpu().tolist() == [[0, 1], [1, 0]] and g['edges'][0][:, 0].cpu().tolist() == [5.0, 2.0]
+    fine = torch.tensor([[0, 8], [2, 0], [3, 1]], dtype=torch.int64).cuda()
+    pp = amd.plan.PoolPlan(fine, [none] * 4)
+    assert pp.cluster.cpu().tolist() == [0, 0, 0] and pp.pooled_loc.cpu().tolist() == [[0, 0]]
+    up = amd.plan.UpsamplePlan(pp.pooled_loc, fine)
+    assert up.parent.cpu().tolist() == [0, 0, 0] and all(e.shape[0] == 0 for e in up.edge_index)
+    fine2 = torch.tensor([[0, 0], [0, 1], [1, 0], [1, 1], [2, 9]], dtype=torch.int64).cuda()
+    pp2 = amd.plan.PoolPlan(fine2, [none] * 4)
+    assert pp2.cluster.cpu().tolist() == [0, 0, 0, 0, 1]
+    up2 = amd.plan.UpsamplePlan(pp2.pooled_loc, fine2)
+    assert [e.cpu().tolist() for e in up2.edge_index] == [[[0, 3], [1, 6]], [[0, 5]], [[0, 4]], [[0, 2]]]

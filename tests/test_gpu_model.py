@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
 from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -106,10 +106,10 @@ def test_unet_forward_one_call(amd, oracle, size, batch):
     got_y, got_g = model(xd, dev_graph())
     for b in range(batch):
         want_y, want_g = oracle.graph_unet_forward(xs[b], copy_graph(graphs[b]), W)
-        assert rel_err(got_y[b].cpu().numpy(), want_y) <= TOL
-        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
+        assert_close(got_y[b].cpu().numpy(), want_y, TOL)
+        assert_close(got_g['global'][b:b + 1].cpu().numpy(), want_g['global'], TOL)
         for q in range(4):
-            assert rel_err(got_g['edges'][q][b].cpu().numpy(), want_g['edges'][q]) <= TOL
+            assert_close(got_g['edges'][q][b].cpu().numpy(), want_g['edges'][q], TOL)
             assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), want_g['edge_index'][q])
     # the layer objects, one library call per layer: same kernels, same order
     model.native_forward = False
@@ -126,7 +126,7 @@ def test_unet_forward_one_call(amd, oracle, size, batch):
     y1, g1 = model(xd[0], {**dev_graph(), 'edges': [to_dev(graphs[0]['edges'][q]) for q in range(4)],
                            'global': to_dev(graphs[0]['global'])})
     assert y1.dim() == 2 and g1['edges'][0].dim() == 2
-    assert rel_err(y1.cpu().numpy(), oracle.graph_unet_forward(xs[0], copy_graph(graphs[0]), W)[0]) <= TOL
+    assert_close(y1.cpu().numpy(), oracle.graph_unet_forward(xs[0], copy_graph(graphs[0]), W)[0], TOL)
 
 
 @pytest.mark.parametrize('size', [(1, 2), (2, 2), (3, 5), (1, 7), (5, 4)])
@@ -138,8 +138,8 @@ def test_unet_forward_tiny_graphs(amd, oracle, size):
     x, graph, _ = make_case(oracle, size[0], size[1], 1.0, dense=True)
     want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
     got_y, got_g = model(to_dev(x), graph_to_dev(graph))
-    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_y.cpu().numpy(), want_y, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     model.native_forward = False
     ref_y, ref_g = model(to_dev(x), graph_to_dev(graph))
     assert torch.equal(got_y, ref_y) and torch.equal(got_g['global'], ref_g['global'])
@@ -172,8 +172,8 @@ def test_unet_forward_random_shapes(amd, oracle, seed):
     got_y, got_g = model(xd, dict(g))
     for b in range(batch):
         want_y, want_g = oracle.graph_unet_forward(xs[b], copy_graph(graphs[b]), W, depth=depth)
-        assert rel_err(got_y[b].cpu().numpy(), want_y) <= TOL, (h, w, depth, b)
-        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= TOL
+        assert_close(got_y[b].cpu().numpy(), want_y, TOL, str((h, w, depth, b)))
+        assert_close(got_g['global'][b:b + 1].cpu().numpy(), want_g['global'], TOL)
     model.native_forward = False
     ref_y, ref_g = model(xd, dict(g))
     assert torch.equal(got_y, ref_y) and torch.equal(got_g['global'], ref_g['global'])
@@ -187,7 +187,7 @@ def test_unet_forward_mixed_widths(amd, oracle):
     x, graph, _ = make_case(oracle, 30, 26, 0.55)
     want_y, _ = oracle.graph_unet_forward(x, copy_graph(graph), W)
     got_y, _ = model(to_dev(x), graph_to_dev(graph))
-    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
+    assert_close(got_y.cpu().numpy(), want_y, TOL)
     model.native_forward = False
     ref_y, _ = model(to_dev(x), graph_to_dev(graph))
     assert torch.equal(got_y, ref_y)
@@ -222,7 +222,7 @@ def test_unet_reload_weights(amd, oracle):
         model = _model(amd, W) if model is None else model.load_weights(W, 'cuda')
         want_y, _ = oracle.graph_unet_forward(x, copy_graph(graph), W)
         got_y, _ = model(to_dev(x), graph_to_dev(graph))
-        assert rel_err(got_y.cpu().numpy(), want_y) <= TOL, seed
+        assert_close(got_y.cpu().numpy(), want_y, TOL, str(seed))
 
 
 def test_unet_forward_errors(amd, oracle):

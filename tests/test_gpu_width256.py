@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
 from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -43,12 +43,12 @@ def test_gn_layer_256(amd, oracle, shape):
     want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
     got_x, got_g = _layer(amd, W, 'L', with_gt)(to_dev(x), graph_to_dev(graph))
     assert tuple(got_x.shape) == (n, 256)
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
     for q in range(4):
         assert tuple(got_g['edges'][q].shape) == (quads[q].shape[0], 64)
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
     assert got_g['global'].shape[1] == (256 if with_gt else g + 256 + 64)
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     # batched call: every sample equals the single-sample call bit for bit
     gb = graph_to_dev(graph)
     gb['edges'] = [e.unsqueeze(0).repeat(2, 1, 1) for e in gb['edges']]
@@ -77,8 +77,8 @@ def test_graph_upsampling_layer_256(amd, oracle):
     up.gcn.load_weights(W, 'U/gcn', 'cuda')
     got_x, got_g = up(to_dev(x), graph_to_dev(coarse), graph_to_dev(fine))
     assert tuple(got_x.shape) == want_x.shape == (node_loc.shape[0], 256)
-    assert rel_err(got_x.cpu().numpy(), want_x) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
 
 
 @pytest.mark.parametrize('units,depth', [(64, 3), (128, 2)])
@@ -92,10 +92,10 @@ def test_graph_unet_wide(amd, oracle, units, depth):
                           use_bias=True, use_global=True, output_activation=None).load_weights(W, 'cuda')
     got_y, got_g = model(to_dev(x), graph_to_dev(graph))
     assert tuple(got_y.shape) == want_y.shape
-    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_y.cpu().numpy(), want_y, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
     for q in range(4):
-        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= TOL
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
 
 
 def test_graph_unet_uniform_256(amd, oracle):
@@ -107,8 +107,8 @@ def test_graph_unet_uniform_256(amd, oracle):
     model = amd.GraphUNet(64, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
                           use_bias=True, use_global=True, min_units=256).load_weights(W, 'cuda')
     got_y, got_g = model(to_dev(x), graph_to_dev(graph))
-    assert rel_err(got_y.cpu().numpy(), want_y) <= TOL
-    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= TOL
+    assert_close(got_y.cpu().numpy(), want_y, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
 
 
 def test_unsupported_width(amd):

@@ -92,6 +92,70 @@ def test_remove_duplicate_edges_known_answer(oracle):
     assert ne.tolist() == [[0, 1], [1, 0]] and nf[:, 0].tolist() == [3.0, 4.0] and ne.dtype == np.int32
 
 
+def test_pooling_dedup_then_selfloop_removal_known_answer(oracle):
+    """graph_pooling_2x2 on 4 nodes in two 2x2 cells, worked by hand (hybrid_gnn.py:391-447):
+    nodes (0,0) (0,1) (0,2) (1,2): max_row + 1 = 2, pos_id = (r//2)*2 + c//2 = [0, 0, 1, 1] -> clusters [0, 0, 1, 1];
+    edges (0,1) (1,2) (0,2) (2,3) (3,1) (1,2) relabel to (0,0) (0,1) (0,1) (1,1) (1,0) (0,1);
+    keys s*4 + r (4 = node count BEFORE pooling) = 0 1 1 5 4 1 -> first occurrences 0 1 5 4 ->
+    (0,0) (0,1) (1,1) (1,0) with feature maxima 1, max(5,3,4) = 5, 7, 2; only then the self-loops go:
+    (0,1) -> 5 and (1,0) -> 2, in that order."""
+    g = {'node_loc': np.array([[0, 0], [0, 1], [0, 2], [1, 2]]),
+         'edge_index': [np.array([[0, 1], [1, 2], [0, 2], [2, 3], [3, 1], [1, 2]], np.int32)] + [np.zeros((0, 2), np.int32)] * 3,
+         'edges': [np.array([[1.], [5.], [3.], [7.], [2.], [4.]], np.float32)] + [np.zeros((0, 1), np.float32)] * 3}
+    x = np.array([[1., -1.], [0., 3.], [2., 2.], [5., -4.]], np.float32)
+    xp, g = oracle.graph_pooling_2x2(x, g)
+    assert xp.tolist() == [[1., 3.], [5., 2.]]
+    assert g['node_loc'].tolist() == [[0, 0], [0, 1]]
+    assert g['edge_index'][0].tolist() == [[0, 1], [1, 0]] and g['edges'][0][:, 0].tolist() == [5.0, 2.0]
+    assert all(g['edge_index'][q].shape == (0, 2) for q in (1, 2, 3))
+
+
+def test_collided_upsampling_cell_known_answer(oracle):
+    """The reference's cell id (row//2) * (max_row + 1) + col//2 merges distinct cells on graphs much
+    wider than high (hybrid_gnn.py:417-423).  Nodes (0,8) (2,0) (3,1): max_row + 1 = 4, cells (0,4),
+    (1,0), (1,0) all get id 4 -> one cluster; its position is the column-wise minimum (0,0).  On the
+    way up (:336-357) the parent sits at 2*(0,0) + 0.5 and the children at offsets (-0.5, 7.5),
+    (1.5, -0.5), (2.5, 0.5): none is one of the four (+-0.5, +-0.5) places, so no child gets an edge."""
+    fine = np.array([[0, 8], [2, 0], [3, 1]])
+    ids, p = oracle.cluster_ids_2x2(fine)
+    assert ids.tolist() == [0, 0, 0] and p == 1
+    coarse = oracle.unsorted_segment_min(fine // 2, ids, p)
+    assert coarse.tolist() == [[0, 0]]
+    parent, lists = oracle.upsample_edges(coarse, fine)
+    assert parent.tolist() == [0, 0, 0] and all(l.shape[0] == 0 for l in lists)
+    # a 4x4 block far enough left keeps its structure next to the collision: (2,0) alone in its cell
+    fine2 = np.array([[0, 0], [0, 1], [1, 0], [1, 1], [2, 9]])
+    ids2, p2 = oracle.cluster_ids_2x2(fine2)      # max_row + 1 = 3: cells 0, 0, 0, 0 and 1*3 + 4 = 7
+    assert ids2.tolist() == [0, 0, 0, 0, 1] and p2 == 2
+    coarse2 = oracle.unsorted_segment_min(fine2 // 2, ids2, p2)
+    parent2, lists2 = oracle.upsample_edges(coarse2, fine2)
+    # children of cell 0: (0,0) -> q3, (0,1) -> q0, (1,1) -> q1, (1,0) -> q2; (2,9) is (even, odd) -> q0
+    assert [l.tolist() for l in lists2] == [[[0, 3], [1, 6]], [[0, 5]], [[0, 4]], [[0, 2]]]
+
+
+def test_column_sum_choice_bracketed_by_float32_orders(oracle):
+    """The oracle's reduce_sum over nodes is the exact sum rounded once.  TensorFlow adds in float32 in
+    an order the reference does not fix; the two extremes -- strictly sequential and pairwise -- on a
+    tensor of the full graph's size both land within 1e-5 (relative) of the oracle's value, so the
+    order-free choice cannot move a feature by more than the parity tolerance."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = np.maximum(rng.standard_normal((96493, 128)).astype(np.float32) * np.float32(0.5) + np.float32(0.2), 0)
+    want = oracle.column_sum(x)[0].astype(np.float64)
+    seq = np.cumsum(x, axis=0, dtype=np.float32)[-1].astype(np.float64)      # ((x0 + x1) + x2) + ...
+    t = x
+    while t.shape[0] > 1:                                                     # balanced tree, float32 at every node
+        if t.shape[0] % 2:
+            t = np.concatenate((t, np.zeros((1, t.shape[1]), np.float32)))
+        t = t[0::2] + t[1::2]
+    pair = t[0].astype(np.float64)
+    err_seq = np.max(np.abs(seq - want) / np.abs(want))
+    err_pair = np.max(np.abs(pair - want) / np.abs(want))
+    assert err_pair <= 2e-7, err_pair
+    assert err_seq <= 1e-5, err_seq
+    # and the float32 value of the exact sum is within half an ulp of it
+    assert np.max(np.abs(want - np.sum(x.astype(np.float64), axis=0)) / np.abs(want)) <= 2.0 ** -24
+
+
 def test_upsample_child_quadrants(oracle):
     # coarse node (k, j): children (2k,2j)->q3, (2k,2j+1)->q0, (2k+1,2j+1)->q1, (2k+1,2j)->q2
     fine = np.array([[r, c] for r in range(4) for c in range(4)])
