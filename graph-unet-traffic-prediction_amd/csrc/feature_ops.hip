@@ -183,8 +183,10 @@ __global__ void k_pool_max(PoolJobs j) {
 // Kernels of one GN layer, templated on UT = units / 128: U = 128*UT output columns per node,
 // u = 32*UT per direction.  UT = 1 is the shipped checkpoint's width, UT = 2 the 256-wide variant.
 
-constexpr int kEdgeGroups = 8;   // 32-edge groups per wave
-constexpr int kEdgesPerBlock = 4 * 32 * kEdgeGroups;
+// The edge kernel's workgroup is four waves of EG consecutive 32-edge groups each: EG = 8 for large
+// edge lists, 2 where that would leave most of the chip idle (every group is ~50 dependent MFMAs).
+constexpr int kEdgeGroupsLarge = 8, kEdgeGroupsSmall = 2;
+constexpr int edges_per_block(int eg) { return 4 * 32 * eg; }
 
 struct LayerPtrs {
   const float* node_emb_b[4];
@@ -440,7 +442,7 @@ struct EdgeArgs {
   int f_e;
   const float* xq;          // [B, N, U] node embeddings, direction q in columns u*q .. u*q+u-1
   const float* ebias;       // [B, 4, u]
-  float* partial;           // [B, 4, gridDim.x, u] column sums of the messages
+  double* partial;          // [B, 4, gridDim.x, u] column sums of the messages
   int relu;
   int sender_only;          // receivers contribute through the bias (graph upsampling)
   float out_scale;          // stored message = out_scale * message (the column sums stay unscaled)
@@ -491,24 +493,27 @@ __device__ inline void gather_edge_rows(const float* __restrict__ xq, const floa
   }
 }
 
-template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY, int UT>
+template <int FE_CHUNKS, bool FE_VEC, bool SENDER_ONLY, int UT, int EG>
 __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
   using Rows = EdgeRows<FE_CHUNKS, SENDER_ONLY, UT>;
   constexpr int CH = Rows::CH;
   constexpr int U = 128 * UT, u = 32 * UT;
   constexpr bool PIPE = UT == 1;   // two row buffers fit the register file only at u = 32
-  __shared__ float Ws[CH * 8 * u];
-  __shared__ float red[4 * u];
+  // Weight image: for 8-row chunk c and column tile t one 1 KiB piece in lane order: lane (lh, li)
+  // finds rows 8c + 4lh + 0..3 of column 32t + li as one float4 (one ds_read_b128 feeds four MFMAs).
+  __shared__ __attribute__((aligned(16))) float Ws[CH * 8 * u];
+  __shared__ double red[4 * u];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int q = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int n_edges = a.n_edges[q];
-  const int64_t block_base = static_cast<int64_t>(blockIdx.x) * kEdgesPerBlock;
-  float colsum[UT];
+  const int64_t block_base = static_cast<int64_t>(blockIdx.x) * edges_per_block(EG);
+  // column sums: float32 over each group's 32 edges in a fixed order, float64 over the groups
+  double colsum[UT];
 #pragma unroll
-  for (int t = 0; t < UT; ++t) colsum[t] = 0.0f;
+  for (int t = 0; t < UT; ++t) colsum[t] = 0.0;
 
   if (block_base < n_edges) {   // uniform over the workgroup
     const float* w = a.edge_w[q];
@@ -519,9 +524,10 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
         v = row < a.f_e ? w[row * u + col] : 0.0f;
       else
         v = w[(a.f_e + row - 8 * FE_CHUNKS) * u + col];
-      Ws[i] = v;
+      Ws[((((row >> 3) * UT + (col >> 5)) * 64) + ((row >> 2) & 1) * 32 + (col & 31)) * 4 + (row & 3)] = v;
     }
     __syncthreads();
+    const float4* wl = reinterpret_cast<const float4*>(Ws) + lane;
     float bias[UT];
 #pragma unroll
     for (int t = 0; t < UT; ++t) bias[t] = a.ebias[(b * 4 + q) * u + 32 * t + li];
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
     const float* xq = a.xq + b * a.n_nodes * static_cast<int64_t>(U) + u * q;
     const float* ef = a.efeat[q] ? a.efeat[q] + b * n_edges * static_cast<int64_t>(a.f_e) : nullptr;
     float* out = a.out[q] + b * n_edges * static_cast<int64_t>(u);
-    const int64_t wave_base = block_base + static_cast<int64_t>(wave) * kEdgeGroups * 32;
+    const int64_t wave_base = block_base + static_cast<int64_t>(wave) * EG * 32;
     auto edge_of = [&](int grp) {
       const int64_t e = wave_base + grp * 32 + li;
       return e < n_edges ? e : static_cast<int64_t>(n_edges) - 1;   // clamped lanes are masked at the store
@@ -544,14 +550,21 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const float a4[4] = {cur.v[c].x, cur.v[c].y, cur.v[c].z, cur.v[c].w};
+        float4 wv[UT];
 #pragma unroll
-        for (int t = 0; t < UT; ++t)
+        for (int t = 0; t < UT; ++t) wv[t] = wl[(c * UT + t) * 64];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], Ws[(8 * c + 4 * lh + j) * u + 32 * t + li],
-                                                          acc[t], 0, 0, 0);
+        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[c].x, wv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[c].y, wv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[c].z, wv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[c].w, wv[t].w, acc[t], 0, 0, 0);
       }
+      float gs[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) gs[t] = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = e0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -560,9 +573,14 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
           for (int t = 0; t < UT; ++t) {
             const float v = activate(acc[t][r] + bias[t], a.relu);
             out[row * u + 32 * t + li] = v * a.out_scale;
-            colsum[t] += v;
+            gs[t] += v;
           }
         }
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        gs[t] += __shfl_xor(gs[t], 32);
+        colsum[t] += static_cast<double>(gs[t]);
       }
     };
     if constexpr (PIPE) {
@@ -575,8 +593,8 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
       auto step = [&](auto full_tag, int grp, Rows& cur, Rows& nxt, int2& sr_nxt, int2& sr_nxt2) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int64_t e0 = wave_base + grp * 32;
-        if (grp + 1 < kEdgeGroups && (FULL || e0 + 32 < n_edges)) {
-          if (grp + 2 < kEdgeGroups) sr_nxt2 = ei[FULL ? e0 + 64 + li : edge_of(grp + 2)];
+        if (grp + 1 < EG && (FULL || e0 + 32 < n_edges)) {
+          if (grp + 2 < EG) sr_nxt2 = ei[FULL ? e0 + 64 + li : edge_of(grp + 2)];
           gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, FULL ? e0 + 32 + li : edge_of(grp + 1),
                                                                sr_nxt, lh, nxt);
         }
@@ -586,24 +604,24 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
       };
       Rows r0, r1;
       int2 sr_a, sr_b;
-      if (wave_base + kEdgeGroups * 32 <= n_edges) {
+      if (wave_base + EG * 32 <= n_edges) {
         sr_a = ei[wave_base + 32 + li];
         gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, wave_base + li, ei[wave_base + li], lh, r0);
 #pragma unroll
-        for (int grp = 0; grp < kEdgeGroups; grp += 2) {
+        for (int grp = 0; grp < EG; grp += 2) {
           step(std::true_type{}, grp, r0, r1, sr_a, sr_b);
           step(std::true_type{}, grp + 1, r1, r0, sr_b, sr_a);
         }
       } else if (wave_base < n_edges) {
         sr_a = ei[edge_of(1)];
         gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, edge_of(0), ei[edge_of(0)], lh, r0);
-        for (int grp = 0; grp < kEdgeGroups && wave_base + grp * 32 < n_edges; grp += 2) {
+        for (int grp = 0; grp < EG && wave_base + grp * 32 < n_edges; grp += 2) {
           step(std::false_type{}, grp, r0, r1, sr_a, sr_b);
           if (wave_base + (grp + 1) * 32 < n_edges) step(std::false_type{}, grp + 1, r1, r0, sr_b, sr_a);
         }
       }
     } else {
-      for (int grp = 0; grp < kEdgeGroups && wave_base + grp * 32 < n_edges; ++grp) {
+      for (int grp = 0; grp < EG && wave_base + grp * 32 < n_edges; ++grp) {
         Rows cur;
         gather_edge_rows<FE_CHUNKS, FE_VEC, SENDER_ONLY, UT>(xq, ef, a.f_e, edge_of(grp), ei[edge_of(grp)], lh, cur);
         multiply(std::false_type{}, wave_base + grp * 32, cur);
@@ -611,13 +629,11 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
     }
   }
 #pragma unroll
-  for (int t = 0; t < UT; ++t) {
-    colsum[t] += __shfl_xor(colsum[t], 32);
+  for (int t = 0; t < UT; ++t)
     if (lh == 0) red[wave * u + 32 * t + li] = colsum[t];
-  }
   __syncthreads();
   if (tid < u) {
-    const float s = ((red[tid] + red[u + tid]) + red[2 * u + tid]) + red[3 * u + tid];
+    const double s = ((red[tid] + red[u + tid]) + red[2 * u + tid]) + red[3 * u + tid];
     a.partial[((b * 4 + q) * gridDim.x + blockIdx.x) * u + tid] = s;
   }
 }
@@ -674,7 +690,7 @@ constexpr int kPreGlobT = 8;   // rows of the glob_transform product fetched ahe
 
 template <int UT>
 __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const double* __restrict__ npart, int n_nblk,
-                                                   const float* __restrict__ epart, int n_eblk, int relu, int64_t b,
+                                                   const double* __restrict__ epart, int n_eblk, int relu, int64_t b,
                                                    double* dpart, float* part, float* gin,
                                                    float* __restrict__ global_out, float* keep,
                                                    const float4 (*head)[kPreGlobT] = nullptr) {
@@ -729,16 +745,16 @@ __device__ __forceinline__ void global_update_body(const LayerPtrs& p, const dou
     const int grp = tid / U, col = tid % U;
     const int q = col / u, c = col % u;
     double s = 0.0;
-    const float* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(u) + c;
+    const double* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(u) + c;
     int i = grp;
     for (; i + 7 * EG < n_eblk; i += 8 * EG) {   // eight partial rows in flight, added in order
-      float v[8];
+      double v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = src[static_cast<int64_t>(i + j * EG) * u];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += static_cast<double>(v[j]);
+      for (int j = 0; j < 8; ++j) s += v[j];
     }
-    for (; i < n_eblk; i += EG) s += static_cast<double>(src[static_cast<int64_t>(i) * u]);
+    for (; i < n_eblk; i += EG) s += src[static_cast<int64_t>(i) * u];
     dpart[grp * U + col] = s;
   }
   __syncthreads();
@@ -779,7 +795,7 @@ template <int UT>
 __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
                                                                  const float* __restrict__ global_in,
                                                                  const double* __restrict__ npart, int n_nblk,
-                                                                 const float* __restrict__ epart, int n_eblk,
+                                                                 const double* __restrict__ epart, int n_eblk,
                                                                  int relu, float* __restrict__ global_out) {
   extern __shared__ __attribute__((aligned(16))) float gsh[];
   double* dpart = reinterpret_cast<double*>(gsh);          // 4096 doubles
@@ -798,7 +814,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update(LayerPtrs p,
 template <int UTC, int UTN>
 __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, const float* __restrict__ global_in,
                                                                  const double* __restrict__ npart, int n_nblk,
-                                                                 const float* __restrict__ epart, int n_eblk, int relu,
+                                                                 const double* __restrict__ epart, int n_eblk, int relu,
                                                                  float* __restrict__ global_out,
                                                                  const float* __restrict__ extra, int extra_width,
                                                                  float* __restrict__ cat_out, LayerPtrs pn,
@@ -833,6 +849,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Which form of the edge kernel a layer on `g` with `batch` samples takes, and how many partial
+// rows per direction it therefore writes: 8 groups per wave unless that leaves fewer than two
+// workgroups per compute unit.
+struct EdgeSplit {
+  int eg, n_eblk;
+};
+
+EdgeSplit edge_split(const gunet_quadgraph* g, int64_t batch) {
+  int max_e = 1;
+  for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
+  const int64_t large = ceil_div(max_e, edges_per_block(kEdgeGroupsLarge));
+  EdgeSplit sp;
+  sp.eg = large * 4 * batch < 2 * static_cast<int64_t>(device_cu_count()) ? kEdgeGroupsSmall : kEdgeGroupsLarge;
+  sp.n_eblk = static_cast<int>(ceil_div(max_e, edges_per_block(sp.eg)));
+  return sp;
+}
+
 struct LayerWorkspace {
   float* xq;      // [B, N, U]            node embeddings (generic) / coarse rows only (upsample)
   float* agg;     // [B, N, U]            aggregated messages (generic) / messages [B, N_fine, u]
@@ -840,9 +873,10 @@ struct LayerWorkspace {
   float* ebias;   // [B, U]
   float* gbias;   // [B, U]
   double* npart;  // [B, n_nblk + 5, U]   column-sum partials of the node MLP (one row per workgroup or wave)
-  float* epart;   // [B, 4, n_eblk, u]
+  double* epart;  // [B, 4, n_eblk_cap, u] column-sum partials of the edge MLP (one row per workgroup)
   void* wpack;    // weight image of the GEMM in flight (split-bf16 matmul modes)
-  int n_nblk, n_eblk;
+  int n_nblk;
+  int n_eblk_cap;   // rows per direction the buffer holds (the small-group form of the edge kernel)
   size_t bytes;
 };
 
@@ -854,7 +888,7 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int unit
   int max_e = 0;
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
   ws.n_nblk = static_cast<int>(ceil_div(g->n_nodes, kRowGroup));
-  ws.n_eblk = static_cast<int>(ceil_div(max_e > 0 ? max_e : 1, kEdgesPerBlock));
+  ws.n_eblk_cap = static_cast<int>(ceil_div(max_e > 0 ? max_e : 1, edges_per_block(kEdgeGroupsSmall)));
   size_t off = 0;
   auto take = [&](size_t floats) {
     float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
@@ -869,7 +903,7 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int unit
   ws.xq = take(bsz * n * U);
   ws.agg = take(bsz * n * U);
   ws.npart = reinterpret_cast<double*>(take(2 * bsz * (ws.n_nblk + 5) * U));
-  ws.epart = take(bsz * 4 * ws.n_eblk * u);
+  ws.epart = reinterpret_cast<double*>(take(2 * bsz * 4 * ws.n_eblk_cap * u));
   ws.wpack = take(wpack_bytes((kMaxCin + 128 * kMaxUT) / kBK + 2, 4) / sizeof(float));
   ws.bytes = off;
   return ws;
@@ -945,63 +979,71 @@ int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu
   return GUNET_OK;
 }
 
-int launch_global_update(const LayerPtrs& p, int ut, const float* global_in, int n_nblk, int relu,
+int launch_global_update(const LayerPtrs& p, int ut, const float* global_in, int n_nblk, int n_eblk, int relu,
                          int32_t batch, const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
   ProfScope prof(kProfGlobalUpdate, stream);
   const size_t lds = sizeof(double) * 4096 + sizeof(float) * (4096 + p.g + 160 * ut);
   if (ut == 1)
     k_global_update<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, ws.npart, n_nblk, ws.epart,
-                                                                ws.n_eblk, relu, global_out);
+                                                                n_eblk, relu, global_out);
   else
     k_global_update<2><<<batch, kSmallThreads, lds, stream>>>(p, global_in, ws.npart, n_nblk, ws.epart,
-                                                                ws.n_eblk, relu, global_out);
+                                                                n_eblk, relu, global_out);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
 template <int UTC>
 int launch_bridge_utc(const LayerPtrs& pc, const LayerPtrs& pn, int utn, size_t lds, int32_t batch, const float* global_in,
-                      int n_nblk, const LayerWorkspace& wc, int relu, float* global_out, const float* extra,
+                      int n_nblk, int n_eblk, const LayerWorkspace& wc, int relu, float* global_out, const float* extra,
                       int extra_width, float* cat_out, int fold_receiver, const LayerWorkspace& wn, hipStream_t stream) {
   if (utn == 1)
-    k_global_bridge<UTC, 1><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, wc.n_eblk,
+    k_global_bridge<UTC, 1><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, n_eblk,
                                                                     relu, global_out, extra, extra_width, cat_out, pn,
                                                                     fold_receiver, wn.nbias, wn.ebias, wn.gbias);
   else
-    k_global_bridge<UTC, 2><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, wc.n_eblk,
+    k_global_bridge<UTC, 2><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, n_eblk,
                                                                     relu, global_out, extra, extra_width, cat_out, pn,
                                                                     fold_receiver, wn.nbias, wn.ebias, wn.gbias);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
-template <int UT>
-int launch_edge_mlp_ut(EdgeArgs& a, int chunks, bool vec, dim3 grid, hipStream_t stream) {
+template <int UT, int EG>
+int launch_edge_mlp_inst(EdgeArgs& a, int chunks, bool vec, dim3 grid, hipStream_t stream) {
   if (a.sender_only) {
-    k_edge_mlp<0, false, true, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<0, false, true, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (chunks == 0) {
-    k_edge_mlp<0, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<0, false, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (vec && chunks == 2) {
-    k_edge_mlp<2, true, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<2, true, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (vec && chunks == 4) {
-    k_edge_mlp<4, true, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<4, true, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (vec && chunks == 8) {
-    k_edge_mlp<8, true, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<8, true, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (chunks == 1) {
-    k_edge_mlp<1, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<1, false, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (chunks == 2) {
-    k_edge_mlp<2, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<2, false, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else if (chunks <= 4) {
-    k_edge_mlp<4, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<4, false, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   } else {
-    k_edge_mlp<8, false, false, UT><<<grid, kThreads, 0, stream>>>(a);
+    k_edge_mlp<8, false, false, UT, EG><<<grid, kThreads, 0, stream>>>(a);
   }
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
-int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const float* const edges[4], int n_eblk,
+template <int UT>
+int launch_edge_mlp_ut(EdgeArgs& a, int chunks, bool vec, int eg, dim3 grid, hipStream_t stream) {
+  return eg == kEdgeGroupsLarge ? launch_edge_mlp_inst<UT, kEdgeGroupsLarge>(a, chunks, vec, grid, stream)
+                                : launch_edge_mlp_inst<UT, kEdgeGroupsSmall>(a, chunks, vec, grid, stream);
+}
+
+int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const float* const edges[4],
                     int32_t batch, hipStream_t stream) {
+  const EdgeSplit split = edge_split(graph, batch);
+  const int n_eblk = split.n_eblk;
   bool any_feat = false, all_feat = true, vec_ok = a.f_e % 8 == 0;
   for (int q = 0; q < 4; ++q) {
     a.edge_index[q] = graph->edge_index[q];
@@ -1028,8 +1070,8 @@ int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const flo
     set_error("edge_mlp: the sender-only form takes no edge features");
     return GUNET_ERR_INVALID;
   }
-  return ut == 1 ? launch_edge_mlp_ut<1>(a, chunks, vec_ok && all_feat, grid, stream)
-                 : launch_edge_mlp_ut<2>(a, chunks, vec_ok && all_feat, grid, stream);
+  return ut == 1 ? launch_edge_mlp_ut<1>(a, chunks, vec_ok && all_feat, split.eg, grid, stream)
+                 : launch_edge_mlp_ut<2>(a, chunks, vec_ok && all_feat, split.eg, grid, stream);
 }
 
 }  // namespace
@@ -1207,7 +1249,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     a.partial = ws.epart;
     a.relu = relu;
     a.out_scale = 1.0f;
-    GUNET_TRY(launch_edge_mlp(a, ut, graph, edges, ws.n_eblk, batch, stream));
+    GUNET_TRY(launch_edge_mlp(a, ut, graph, edges, batch, stream));
   }
 
   // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
@@ -1284,7 +1326,8 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
 
   if (n_partials_out) *n_partials_out = n_partials;
   if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-  return launch_global_update(p, ut, global_in, n_partials, relu, batch, ws, global_out, stream);
+  return launch_global_update(p, ut, global_in, n_partials, edge_split(graph, batch).n_eblk, relu, batch, ws, global_out,
+                              stream);
 }
 
 int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w, int32_t batch,
@@ -1345,7 +1388,7 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
     a.relu = relu;
     a.sender_only = 1;
     a.out_scale = 1.0f / (3 + 1);
-    GUNET_TRY(launch_edge_mlp(a, ut, graph, nullptr, ws.n_eblk, batch, stream));
+    GUNET_TRY(launch_edge_mlp(a, ut, graph, nullptr, batch, stream));
   }
 
   // node MLP.  Coarse rows: only the x columns are non-zero and only their column sums are used
@@ -1396,7 +1439,8 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
   }
   if (n_partials_out) *n_partials_out = tiles_total;
   if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-  return launch_global_update(p, ut, global_in, tiles_total, relu, batch, ws, global_out, stream);
+  return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, batch).n_eblk, relu, batch, ws, global_out,
+                              stream);
 }
 
 int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int n_partials, const float* global_in,
@@ -1418,10 +1462,11 @@ int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int
   GUNET_REQUIRE(lds <= 64 * 1024, "gn_bridge: global vectors of %d and %d floats do not fit", pc.g, pn.g);
   const int relu = activation == GUNET_ACT_RELU;
   ProfScope prof(kProfBridge, stream);
-  return utc == 1 ? launch_bridge_utc<1>(pc, pn, utn, lds, batch, global_in, n_partials, wc, relu, global_out, extra,
-                                         extra_width, cat_out, next_fold_receiver, wn, stream)
-                  : launch_bridge_utc<2>(pc, pn, utn, lds, batch, global_in, n_partials, wc, relu, global_out, extra,
-                                         extra_width, cat_out, next_fold_receiver, wn, stream);
+  const int n_eblk = edge_split(cur_graph, batch).n_eblk;
+  return utc == 1 ? launch_bridge_utc<1>(pc, pn, utn, lds, batch, global_in, n_partials, n_eblk, wc, relu, global_out,
+                                         extra, extra_width, cat_out, next_fold_receiver, wn, stream)
+                  : launch_bridge_utc<2>(pc, pn, utn, lds, batch, global_in, n_partials, n_eblk, wc, relu, global_out,
+                                         extra, extra_width, cat_out, next_fold_receiver, wn, stream);
 }
 
 }  // namespace gunet

@@ -27,10 +27,14 @@ __device__ inline float activate(float v, int relu) { return relu ? fmaxf(v, 0.0
 // k of each MFMA; the k order inside a chunk is a fixed permutation, the same for the weights).
 // Only the weight tile goes through LDS (double-buffered, one barrier per K tile); the next A
 // tile is prefetched in registers.  Epilogue: bias, activation, optional row scatter, and the
-// column sums of every wave's 32 rows (fixed order: 16 rows per lane, then the two half-waves).
-// `bx`: this workgroup's row tile within the problem `g`.
+// column sums: per wave the float32 sum of its 32 rows (16 rows per lane in a fixed order, then the
+// two half-waves), added in float64 over the workgroup's row tiles and then over its four waves.
+// A workgroup walks the row tiles wg * tpw .. wg * tpw + tpw - 1 of problem `g` (tpw > 1 only to
+// keep the number of column-sum partial rows small) and writes partial row `wg`.  `ct` shifts the
+// launch's columns by 32 * ct: small launches are cut into NT = 1 column slices (grid z) so that
+// four times as many waves share the matrix work.
 template <int NT>
-__device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const int bx) {
+__device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, const int tpw, const int ct) {
   constexpr int BN = 32 * NT;
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BN];
   __shared__ __attribute__((aligned(16))) float Stage[4][16 * 32];   // epilogue: one per wave
@@ -39,14 +43,10 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const int bx) {
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.y;
-  const int row0 = bx * kBM;
-  const int my_row = row0 + 32 * wave + li;
-  const bool row_ok = my_row < g.n_rows;
+  const int col0 = g.out_col0 + 32 * ct;
 
   int n_tiles = 0;
   for (int s = 0; s < g.n_seg; ++s) n_tiles += (g.seg[s].k + kBK - 1) / kBK;
-
-  float4 b_reg[NT];
   auto locate = [&](int t, int& s, int& k0) {
     s = 0;
     while (true) {
@@ -57,147 +57,167 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const int bx) {
     }
     k0 = t * kBK;
   };
-  auto load_a = [&](int t, float4 (&a)[4]) {
-    int s, k0;
-    locate(t, s, k0);
-    const GemmSeg& sg = g.seg[s];
-    const float* p = sg.a + (b * g.n_rows + my_row) * static_cast<int64_t>(sg.lda) + k0 + 4 * lh;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (row_ok && k0 + 8 * c + 4 * lh < sg.k)
-        a[c] = *reinterpret_cast<const float4*>(p + 8 * c);
-      else
-        a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  // thread (kr = tid / 8, c4 = tid % 8) stages row k0+kr, floats 4c4..4c4+3 of every column tile
-  auto load_b = [&](int t) {
-    int s, k0;
-    locate(t, s, k0);
-    const GemmSeg& sg = g.seg[s];
-    const int k = k0 + (tid >> 3);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (k < sg.k)
-        b_reg[j] = *reinterpret_cast<const float4*>(sg.w[j] + static_cast<int64_t>(k) * sg.ldw + 4 * (tid & 7));
-      else
-        b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto store_b = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-      *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) * BN + 32 * j + 4 * (tid & 7)]) = b_reg[j];
-  };
 
-  f32x16 acc[NT];
   float bias_v[NT];   // loaded up front: a load inside the epilogue would drain its stores
+  double csd[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * n + li] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * (ct + n) + li] : 0.0f;
+    csd[n] = 0.0;
   }
 
-  float4 a_cur[4], a_nxt[4];
-  load_a(0, a_cur);
-  load_b(0);
-  store_b(0);
-  __syncthreads();
-  for (int t = 0; t < n_tiles; ++t) {
-    const bool more = t + 1 < n_tiles;
-    if (more) {
-      load_b(t + 1);
-      load_a(t + 1, a_nxt);
-    }
-    const float* bs = Bs[t & 1];
+  const int row_tiles = (g.n_rows + kBM - 1) / kBM;
+  const int bx_end = min((wg + 1) * tpw, row_tiles);
+  for (int bx = wg * tpw; bx < bx_end; ++bx) {
+    const int row0 = bx * kBM;
+    const int my_row = row0 + 32 * wave + li;
+    const bool row_ok = my_row < g.n_rows;
+
+    float4 b_reg[NT];
+    auto load_a = [&](int t, float4 (&a)[4]) {
+      int s, k0;
+      locate(t, s, k0);
+      const GemmSeg& sg = g.seg[s];
+      const float* p = sg.a + (b * g.n_rows + my_row) * static_cast<int64_t>(sg.lda) + k0 + 4 * lh;
 #pragma unroll
-    for (int c = 0; c < kBK / 8; ++c) {
-      const float a4[4] = {a_cur[c].x, a_cur[c].y, a_cur[c].z, a_cur[c].w};
+      for (int c = 0; c < 4; ++c) {
+        if (row_ok && k0 + 8 * c + 4 * lh < sg.k)
+          a[c] = *reinterpret_cast<const float4*>(p + 8 * c);
+        else
+          a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    // thread (kr = tid / 8, c4 = tid % 8) stages row k0+kr, floats 4c4..4c4+3 of every column tile
+    auto load_b = [&](int t) {
+      int s, k0;
+      locate(t, s, k0);
+      const GemmSeg& sg = g.seg[s];
+      const int k = k0 + (tid >> 3);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (k < sg.k)
+          b_reg[j] = *reinterpret_cast<const float4*>(sg.w[ct + j] + static_cast<int64_t>(k) * sg.ldw + 4 * (tid & 7));
+        else
+          b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) * BN + 32 * j + 4 * (tid & 7)]) = b_reg[j];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    float4 a_cur[4], a_nxt[4];
+    load_a(0, a_cur);
+    load_b(0);
+    store_b(0);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+      const bool more = t + 1 < n_tiles;
+      if (more) {
+        load_b(t + 1);
+        load_a(t + 1, a_nxt);
+      }
+      const float* bs = Bs[t & 1];
+#pragma unroll
+      for (int c = 0; c < kBK / 8; ++c) {
+        const float a4[4] = {a_cur[c].x, a_cur[c].y, a_cur[c].z, a_cur[c].w};
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float bv = bs[(8 * c + 4 * lh + j) * BN + 32 * n + li];
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bv, acc[n], 0, 0, 0);
+          }
+        }
+      }
+      if (more) store_b((t + 1) & 1);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
+    }
+
+    // accumulator register r of lane (li, lh) is row (r&3) + 8*(r>>2) + 4*lh of the wave, column li
+    float cs[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) cs[n] = 0.0f;
+    const int wrow0 = row0 + 32 * wave;
+    if (g.row_map == nullptr) {
+      // 16 rows x 32 columns at a time through the wave's own LDS, picked up row-wise: a store
+      // instruction then writes eight full 128-byte lines instead of two
+      float* stage = Stage[wave];
+      const int srow = lane >> 3, scol = 4 * (lane & 7);
+      float* obase = g.out ? g.out + (b * g.out_rows + wrow0 + srow) * static_cast<int64_t>(g.ldo) + col0 + scol
+                           : nullptr;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float bv = bs[(8 * c + 4 * lh + j) * BN + 32 * n + li];
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bv, acc[n], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8) {
+            const int r = 8 * h + r8;
+            const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;
+            const float v = activate(acc[n][r] + bias_v[n], g.relu);
+            stage[rl * 32 + li] = v;
+            if (wrow0 + 16 * h + rl < g.n_rows) cs[n] += v;
+          }
+          if (obase) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
+              if (wrow0 + 16 * h + 8 * i + srow < g.n_rows)
+                *reinterpret_cast<float4*>(obase + static_cast<int64_t>(16 * h + 8 * i) * g.ldo + 32 * n) = v;
+            }
+          }
         }
       }
-    }
-    if (more) store_b((t + 1) & 1);
-    __syncthreads();
+    } else {
+      float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + col0 + li : nullptr;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
-  }
-
-  // accumulator register r of lane (li, lh) is row (r&3) + 8*(r>>2) + 4*lh of the wave, column li
-  float cs[NT];
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.n_rows) {
+          const int64_t orow = g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) cs[n] = 0.0f;
-  const int wrow0 = row0 + 32 * wave;
-  if (g.row_map == nullptr) {
-    // 16 rows x 32 columns at a time through the wave's own LDS, picked up row-wise: a store
-    // instruction then writes eight full 128-byte lines instead of two
-    float* stage = Stage[wave];
-    const int srow = lane >> 3, scol = 4 * (lane & 7);
-    float* obase = g.out ? g.out + (b * g.out_rows + wrow0 + srow) * static_cast<int64_t>(g.ldo) + g.out_col0 + scol
-                         : nullptr;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-          const int r = 8 * h + r8;
-          const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;
-          const float v = activate(acc[n][r] + bias_v[n], g.relu);
-          stage[rl * 32 + li] = v;
-          if (wrow0 + 16 * h + rl < g.n_rows) cs[n] += v;
-        }
-        if (obase) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
-            if (wrow0 + 16 * h + 8 * i + srow < g.n_rows)
-              *reinterpret_cast<float4*>(obase + static_cast<int64_t>(16 * h + 8 * i) * g.ldo + 32 * n) = v;
+          for (int n = 0; n < NT; ++n) {
+            const float v = activate(acc[n][r] + bias_v[n], g.relu);
+            if (obase) obase[orow * g.ldo + 32 * n] = v;
+            cs[n] += v;
           }
         }
       }
     }
-  } else {
-    float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + g.out_col0 + li : nullptr;
+    if (g.colsum != nullptr) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < g.n_rows) {
-        const int64_t orow = g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const float v = activate(acc[n][r] + bias_v[n], g.relu);
-          if (obase) obase[orow * g.ldo + 32 * n] = v;
-          cs[n] += v;
-        }
+      for (int n = 0; n < NT; ++n) {
+        cs[n] += __shfl_xor(cs[n], 32);
+        csd[n] += static_cast<double>(cs[n]);
       }
     }
   }
-  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' 32-row sums added in float64
+  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' sums added in order
     double* red = reinterpret_cast<double*>(&Stage[0][0]);   // 4 * BN <= 512 doubles; the staging tiles are no longer in use
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      cs[n] += __shfl_xor(cs[n], 32);
-      if (lh == 0) red[wave * BN + 32 * n + li] = static_cast<double>(cs[n]);
-    }
+    for (int n = 0; n < NT; ++n)
+      if (lh == 0) red[wave * BN + 32 * n + li] = csd[n];
     __syncthreads();
     if (tid < BN) {
       const double s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + bx) * g.colsum_ld + g.out_col0 + tid] = s;
+      g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + wg) * g.colsum_ld + col0 + tid] = s;
     }
   }
 }
 
 template <int NT>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
-  gemm_f32_tile<NT>(g, blockIdx.x);
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g, int tpw) {
+  gemm_f32_tiles<NT>(g, blockIdx.x, tpw, blockIdx.z);
 }
 
 // Up to four independent problems of the same column-tile count in one grid (the four quadrant
@@ -205,25 +225,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g) {
 constexpr int kGemmGroup = 4;
 struct GemmGroup {
   GemmArgs p[kGemmGroup];
-  unsigned block_end[kGemmGroup];   // running total of the problems' row tiles
+  unsigned block_end[kGemmGroup];   // running total of the problems' workgroups
+  int tpw[kGemmGroup];              // row tiles per workgroup of each problem
 };
 
 template <int NT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_f32_group(GemmGroup gg) {
   int i = 0;
   while (i < kGemmGroup - 1 && blockIdx.x >= gg.block_end[i]) ++i;
-  gemm_f32_tile<NT>(gg.p[i], static_cast<int>(blockIdx.x - (i > 0 ? gg.block_end[i - 1] : 0u)));
+  gemm_f32_tiles<NT>(gg.p[i], static_cast<int>(blockIdx.x - (i > 0 ? gg.block_end[i - 1] : 0u)), gg.tpw[i], blockIdx.z);
 }
 
 // Weights-resident variant (the weight matrix must fit LDS: 32 * NKT * 32 * NT floats): a workgroup
 // of twelve waves (eight for the 128-column gathering form) copies the whole weight matrix into
-// LDS once, then its waves work on their own, with no barrier after the
-// first: every sample's 32-row groups are dealt out in runs of `gpw` consecutive groups, one run
-// per wave (`wps` waves per sample).  The A tile of step t+1 -- the next group's first tile at a
+// LDS once, then its waves work on their own, with no barrier between the first and the one
+// that closes the kernel: every sample's 32-row groups are dealt out in runs of `gpw` consecutive
+// groups, one run per wave, `bps` workgroups per sample (a workgroup never straddles two samples).  The A tile of step t+1 -- the next group's first tile at a
 // group's last step -- is requested before the MFMAs of step t, into the other of two register
 // buffers, so a wave always has one tile in flight behind its matrix work and the waves of a SIMD
 // drift apart instead of stalling together.  Rows past the end of a sample are clamped for the
-// loads and masked in the epilogue.  Column sums: one partial row per wave (its whole run).
+// loads and masked in the epilogue.  Column sums: one partial row per workgroup (its waves' runs,
+// added in wave order in float64 after the closing barrier).
 constexpr int kResWaves = 12;
 constexpr int kResThreads = 64 * kResWaves;
 constexpr int kResGatherWaves = 8;   // the 128-column gathering variant needs more registers per wave
@@ -239,7 +261,7 @@ constexpr size_t kResMaxLds = 160 * 1024;   // most LDS a workgroup may ask for 
 // first piece of that tile and zeroed.
 template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
 __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(
-    GemmArgs g, int groups_per_sample, int wps, int gpw, int batch) {
+    GemmArgs g, int groups_per_sample, int bps, int gpw) {
   static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
   static_assert(!RAGGED || (!GATHER && !BF16), "the ragged form is float32 without gathering");
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
@@ -293,12 +315,11 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   }
   __syncthreads();
 
-  const int wid = blockIdx.x * kWaves + wave;
-  const int b = wid / wps;
-  if (b >= batch) return;
-  const int slot = wid - b * wps;
-  int grp = slot * gpw;
+  const int b = blockIdx.x / bps;
+  const int blk = blockIdx.x - b * bps;
+  int grp = (blk * kWaves + wave) * gpw;
   const int grp_end = min(grp + gpw, groups_per_sample);
+  const bool has_work = grp < grp_end;   // the last workgroup of a sample may have idle waves
 
   // this lane's (clamped) row of group grp_, counted over all samples
   auto lane_row = [&](int grp_) {
@@ -471,10 +492,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     }
   };
 
-  uint32_t cur = lane_row(grp);
+  uint32_t cur = lane_row(has_work ? grp : 0);
   float4 a0[4], a1[4];
-  load_tile(cur, 0, a0);
-  while (true) {
+  if (has_work) load_tile(cur, 0, a0);
+  while (has_work) {
     const bool has_next = grp + 1 < grp_end;
     const uint32_t nxt = lane_row(has_next ? grp + 1 : grp);   // a finished wave re-reads its own rows: harmless
 #pragma unroll
@@ -538,12 +559,19 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     ++grp;
     cur = nxt;
   }
-  if (g.colsum != nullptr) {
-    double* dst = g.colsum + (static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + slot) * g.colsum_ld +
-                  g.out_col0 + li;
+  if (g.colsum != nullptr) {   // uniform over the grid
+    // every wave leaves its run's sums in its own (now idle) staging area; thread c then adds the
+    // waves' values of column c in wave order
+    double* red = reinterpret_cast<double*>(res_smem + (BF16 ? 16 : 32) * NKT * BN);
 #pragma unroll
     for (int n = 0; n < NT; ++n)
-      if (lh == 0) dst[32 * n] = cs[n];
+      if (lh == 0) red[wave * 256 + 32 * n + li] = cs[n];
+    __syncthreads();
+    if (tid < BN) {
+      double s = red[tid];
+      for (int w = 1; w < kWaves; ++w) s += red[w * 256 + tid];
+      g.colsum[(static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + blk) * g.colsum_ld + g.out_col0 + tid] = s;
+    }
   }
 }
 
@@ -895,18 +923,19 @@ inline int resident_block_waves(const GemmArgs& g, int nt) {
   return (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves;
 }
 
-// Work split of the resident kernel: every sample's row groups in runs of gpw, wps waves per sample.
+// Work split of the resident kernel: every sample's row groups in runs of gpw, one run per wave,
+// bps workgroups per sample (about one workgroup per compute unit in all).
 struct ResidentSplit {
-  int groups, wps, gpw;
+  int groups, bps, gpw;
 };
 
 inline ResidentSplit resident_split(int n_rows, int64_t batch, int block_waves) {
   ResidentSplit r;
   r.groups = static_cast<int>(ceil_div(n_rows, kRowGroup));
-  const int64_t waves = static_cast<int64_t>(device_cu_count()) * block_waves;
-  const int per_sample = static_cast<int>(std::max<int64_t>(1, waves / batch));
-  r.gpw = static_cast<int>(ceil_div(r.groups, std::min(per_sample, r.groups)));
-  r.wps = static_cast<int>(ceil_div(r.groups, r.gpw));
+  const int64_t want = std::max<int64_t>(1, device_cu_count() / batch);                 // workgroups per sample
+  const int64_t bps = std::min<int64_t>(want, ceil_div(r.groups, block_waves));
+  r.gpw = static_cast<int>(ceil_div(r.groups, bps * block_waves));
+  r.bps = static_cast<int>(ceil_div(r.groups, static_cast<int64_t>(r.gpw) * block_waves));   // no empty workgroups
   return r;
 }
 
@@ -919,11 +948,52 @@ bool takes_resident(const GemmArgs& g, int nt, int64_t batch, const void* wpack)
 }
 inline bool takes_split(const void* wpack) { return mode_pieces(g_matmul_mode) > 0 && wpack != nullptr; }
 
+// Row tiles (of 128 rows) one workgroup of the tiled float32 kernel walks.  More than one only when
+// the launch writes column sums, so that a sample leaves at most about 2 * CUs / batch (32 .. 256)
+// partial rows for the per-sample kernel that adds them up.
+inline int tiled_tiles_per_wg(const GemmArgs& g, int64_t batch, bool with_colsum) {
+  if (!with_colsum) return 1;
+  const int64_t tiles = ceil_div(g.n_rows, kBM);
+  const int64_t rows = std::min<int64_t>(256, std::max<int64_t>(32, 2 * device_cu_count() / std::max<int64_t>(1, batch)));
+  return static_cast<int>(std::max<int64_t>(1, ceil_div(tiles, rows)));
+}
+
 // Rows of column-sum partials per sample that a launch writes (from colsum_tile0 on).
 int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
   if (g.n_rows == 0) return 0;
-  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, resident_block_waves(g, nt)).wps;
-  return static_cast<int>(ceil_div(g.n_rows, kBM));
+  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, resident_block_waves(g, nt)).bps;
+  const int64_t tiles = ceil_div(g.n_rows, kBM);
+  if (takes_split(wpack)) return static_cast<int>(tiles);
+  return static_cast<int>(ceil_div(tiles, tiled_tiles_per_wg(g, batch, true)));
+}
+
+// Small launches of the tiled kernel are cut into 32-column slices: the matrix work of a 128-row
+// tile is then shared by four workgroups instead of sitting in one wave per 32 rows.
+inline bool tiled_slices(int64_t workgroups, int nt) {
+  return nt > 1 && workgroups < 2 * static_cast<int64_t>(device_cu_count());
+}
+
+int launch_tiled(int nt, bool group, dim3 grid, hipStream_t stream, const GemmArgs* g, int tpw, const GemmGroup* gg) {
+  (void)group;
+  if (g != nullptr) {
+    switch (nt) {
+      case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      case 2: k_gemm_f32<2><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      case 3: k_gemm_f32<3><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      case 4: k_gemm_f32<4><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      default: set_error("launch_gemm: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+    }
+  } else {
+    switch (nt) {
+      case 1: k_gemm_f32_group<1><<<grid, kThreads, 0, stream>>>(*gg); break;
+      case 2: k_gemm_f32_group<2><<<grid, kThreads, 0, stream>>>(*gg); break;
+      case 3: k_gemm_f32_group<3><<<grid, kThreads, 0, stream>>>(*gg); break;
+      case 4: k_gemm_f32_group<4><<<grid, kThreads, 0, stream>>>(*gg); break;
+      default: set_error("launch_gemm_group: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+    }
+  }
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
 }
 
 template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
@@ -941,9 +1011,8 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   }
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
-  const int blocks = static_cast<int>(ceil_div(batch * sp.wps, kWaves));
-  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.wps, sp.gpw,
-                                                                                     static_cast<int>(batch));
+  const int blocks = static_cast<int>(batch * sp.bps);
+  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.bps, sp.gpw);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
@@ -1003,15 +1072,13 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
     return launch_gemm_split<1>(g, nt, grid, wp, stream);
   }
   if (resident) return launch_gemm_resident(g, nt, batch, stream);
-  switch (nt) {
-    case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(g); break;
-    case 2: k_gemm_f32<2><<<grid, kThreads, 0, stream>>>(g); break;
-    case 3: k_gemm_f32<3><<<grid, kThreads, 0, stream>>>(g); break;
-    case 4: k_gemm_f32<4><<<grid, kThreads, 0, stream>>>(g); break;
-    default: set_error("launch_gemm: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+  const int tpw = tiled_tiles_per_wg(g, batch, g.colsum != nullptr);
+  grid.x = static_cast<unsigned>(ceil_div(ceil_div(g.n_rows, kBM), tpw));
+  if (tiled_slices(static_cast<int64_t>(grid.x) * batch, nt)) {
+    grid.z = static_cast<unsigned>(nt);
+    nt = 1;
   }
-  GUNET_LAUNCH_CHECK();
-  return GUNET_OK;
+  return launch_tiled(nt, false, grid, stream, &g, tpw, nullptr);
 }
 
 // Several problems with the same column-tile count and batch as one launch of the tiled float32
@@ -1036,22 +1103,21 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
       GemmArgs& g = gg.p[i];
       if (g.out_rows == 0) g.out_rows = g.n_rows;
       if (g.colsum_ld == 0) g.colsum_ld = 32 * nt;
-      blocks += static_cast<unsigned>(ceil_div(g.n_rows, kBM));
+      gg.tpw[i] = tiled_tiles_per_wg(g, batch, g.colsum != nullptr);
+      blocks += static_cast<unsigned>(ceil_div(ceil_div(g.n_rows, kBM), gg.tpw[i]));
       for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
+    } else {
+      gg.tpw[i] = 1;
     }
     gg.block_end[i] = blocks;
   }
   dim3 grid(blocks, static_cast<unsigned>(batch));
   ProfScope prof(kProfGemmTiled, stream, flops);
-  switch (nt) {
-    case 1: k_gemm_f32_group<1><<<grid, kThreads, 0, stream>>>(gg); break;
-    case 2: k_gemm_f32_group<2><<<grid, kThreads, 0, stream>>>(gg); break;
-    case 3: k_gemm_f32_group<3><<<grid, kThreads, 0, stream>>>(gg); break;
-    case 4: k_gemm_f32_group<4><<<grid, kThreads, 0, stream>>>(gg); break;
-    default: set_error("launch_gemm_group: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+  if (tiled_slices(static_cast<int64_t>(blocks) * batch, nt)) {
+    grid.z = static_cast<unsigned>(nt);
+    nt = 1;
   }
-  GUNET_LAUNCH_CHECK();
-  return GUNET_OK;
+  return launch_tiled(nt, true, grid, stream, nullptr, 0, &gg);
 }
 
 }  // namespace gunet
