@@ -275,8 +275,8 @@ __device__ inline float combine_rows(const float* part, int n, int ld, int col) 
 }
 
 // Per sample: the chained global transforms (hybrid_gnn.py:98-99), folded into the bias each
-// direction's edge MLP sees; the node MLP's global columns folded into its bias (:122-125);
-// and the four node-embedding biases laid side by side.  Everything that does not depend on the
+// direction's edge MLP sees, and the node MLP's global columns folded into its bias (:122-125).
+// Everything that does not depend on the
 // chain (the node-MLP bias, the constant receiver term of the upsampling form, and the weights the
 // later chain steps need) is fetched first, so the chain itself only waits on LDS.
 // Split in two so that a caller with other work to do first (k_global_bridge) can have the weight
@@ -299,7 +299,7 @@ struct ProloguePre {
 
 template <int UT, bool DEEP>
 __device__ __forceinline__ void prologue_prefetch(const LayerPtrs& p, int relu, int fold_receiver, int64_t b,
-                                                  float* __restrict__ nbias, ProloguePre<UT>& pre) {
+                                                  ProloguePre<UT>& pre) {
   constexpr int U = 128 * UT, u = 32 * UT;
   constexpr int QC = U / 4;
   constexpr int CG = ProloguePre<UT>::CG, CR = ProloguePre<UT>::CR, EG = ProloguePre<UT>::EG, ER = ProloguePre<UT>::ER;
@@ -335,7 +335,6 @@ __device__ __forceinline__ void prologue_prefetch(const LayerPtrs& p, int relu, 
         r = fmaf(activate(p.node_emb_b[eq] ? p.node_emb_b[eq][k] : 0.0f, relu), wr[k * u + ej], r);
       pre.e_const += r;
     }
-    if (b == 0) nbias[tid] = p.node_emb_b[eq] ? p.node_emb_b[eq][ej] : 0.0f;
   }
 }
 
@@ -418,7 +417,6 @@ template <int UT>
 __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
                                                                   const float* __restrict__ global_in,
                                                                   int relu, int fold_receiver,
-                                                                  float* __restrict__ nbias,
                                                                   float* __restrict__ ebias,
                                                                   float* __restrict__ gbias) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
   const int64_t b = blockIdx.x;
   for (int k = threadIdx.x; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
   ProloguePre<UT> pre;
-  prologue_prefetch<UT, false>(p, relu, fold_receiver, b, nbias, pre);
+  prologue_prefetch<UT, false>(p, relu, fold_receiver, b, pre);
   prologue_compute<UT, false>(p, gl, relu, b, part, gq, ebias, gbias, pre);
 }
 
@@ -818,7 +816,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
                                                                  float* __restrict__ global_out,
                                                                  const float* __restrict__ extra, int extra_width,
                                                                  float* __restrict__ cat_out, LayerPtrs pn,
-                                                                 int fold_receiver, float* __restrict__ nbias,
+                                                                 int fold_receiver,
                                                                  float* __restrict__ ebias, float* __restrict__ gbias) {
   extern __shared__ __attribute__((aligned(16))) float bsh[];
   double* dpart = reinterpret_cast<double*>(bsh);          // 4096 doubles
@@ -830,7 +828,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
   for (int k = threadIdx.x; k < pc.g; k += blockDim.x) gin[k] = global_in[b * pc.g + k];
   // every weight the two stages will want first is requested now, behind the column sums
   ProloguePre<UTN> pre;
-  prologue_prefetch<UTN, true>(pn, relu, fold_receiver, b, nbias, pre);
+  prologue_prefetch<UTN, true>(pn, relu, fold_receiver, b, pre);
   float4 head[kPreGlobT];
   if (pc.globt_w != nullptr)
     matvec_head_load<128 * UTC, kPreGlobT>(pc.globt_w, pc.g + 160 * UTC, threadIdx.x / (32 * UTC),
@@ -869,7 +867,6 @@ EdgeSplit edge_split(const gunet_quadgraph* g, int64_t batch) {
 struct LayerWorkspace {
   float* xq;      // [B, N, U]            node embeddings (generic) / coarse rows only (upsample)
   float* agg;     // [B, N, U]            aggregated messages (generic) / messages [B, N_fine, u]
-  float* nbias;   // [U]
   float* ebias;   // [B, U]
   float* gbias;   // [B, U]
   double* npart;  // [B, n_nblk + 5, U]   column-sum partials of the node MLP (one row per workgroup or wave)
@@ -897,7 +894,6 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int unit
   };
   // the folded biases come first, at offsets that depend on the batch only: the kernel that finishes
   // one layer's global and prepares the next layer's biases works on two layouts at once
-  ws.nbias = take(128 * kMaxUT);
   ws.ebias = take(bsz * 128 * kMaxUT);
   ws.gbias = take(bsz * 128 * kMaxUT);
   ws.xq = take(bsz * n * U);
@@ -970,10 +966,10 @@ int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu
   ProfScope prof(kProfPrologue, stream);
   const size_t lds = sizeof(float) * (4096 + p.g + 4 * 32 * ut);
   if (ut == 1)
-    k_layer_prologue<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver, ws.nbias,
+    k_layer_prologue<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver,
                                                                  ws.ebias, ws.gbias);
   else
-    k_layer_prologue<2><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver, ws.nbias,
+    k_layer_prologue<2><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver,
                                                                  ws.ebias, ws.gbias);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
@@ -1000,11 +996,11 @@ int launch_bridge_utc(const LayerPtrs& pc, const LayerPtrs& pn, int utn, size_t 
   if (utn == 1)
     k_global_bridge<UTC, 1><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, n_eblk,
                                                                     relu, global_out, extra, extra_width, cat_out, pn,
-                                                                    fold_receiver, wn.nbias, wn.ebias, wn.gbias);
+                                                                    fold_receiver, wn.ebias, wn.gbias);
   else
     k_global_bridge<UTC, 2><<<batch, kSmallThreads, lds, stream>>>(pc, global_in, wc.npart, n_nblk, wc.epart, n_eblk,
                                                                     relu, global_out, extra, extra_width, cat_out, pn,
-                                                                    fold_receiver, wn.nbias, wn.ebias, wn.gbias);
+                                                                    fold_receiver, wn.ebias, wn.gbias);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
@@ -1233,7 +1229,8 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     auto w_of = [&](int s, int col) {
       return w->node_emb_w[col / u] + (s == 0 ? 0 : static_cast<int64_t>(c_a) * u) + col % u;
     };
-    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.nbias, 0, ws.xq, nullptr, w_of, ws.wpack, stream));
+    auto b_of = [&](int col) { return w->node_emb_b[col / u] ? w->node_emb_b[col / u] + col % u : nullptr; };
+    GUNET_TRY(launch_gemm_columns_tile_bias(g, U, batch, b_of, ws.xq, w_of, ws.wpack, stream));
   }
 
   {  // edge MLP + message column sums (hybrid_gnn.py:93-108)
@@ -1365,7 +1362,8 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
     g.n_rows = n_coarse;
     g.relu = relu;
     auto w_of = [&](int, int col) { return w->node_emb_w[col / u] + col % u; };
-    GUNET_TRY(launch_gemm_columns(g, U, batch, ws.nbias, 0, ws.xq, nullptr, w_of, ws.wpack, stream));
+    auto b_of = [&](int col) { return w->node_emb_b[col / u] ? w->node_emb_b[col / u] + col % u : nullptr; };
+    GUNET_TRY(launch_gemm_columns_tile_bias(g, U, batch, b_of, ws.xq, w_of, ws.wpack, stream));
   }
 
   // messages: every edge goes (coarse parent -> fine node); edge features are zero.  Stored

@@ -25,6 +25,8 @@ struct GemmArgs {
   int n_rows;                 // A rows per sample
   const float* bias;          // [.., 32*NT] or null
   int bias_stride;            // floats between samples (0 = shared)
+  const float* bias_tile[4];  // with bias_by_tile: 32 floats of bias per column tile (null = none), shared
+  int bias_by_tile;           //   by all samples -- the four directions' embedding biases where they lie
   float* out;                 // sample 0; null = compute the column sums only
   int ldo;
   int out_col0;               // first output column of this launch
@@ -117,6 +119,21 @@ int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float
   const int nt = columns_nt(g);
   for (int col0 = 0; col0 < units; col0 += 32 * nt)
     GUNET_TRY(launch_gemm(columns_block(g, units, col0, nt, bias, bias_stride, out, colsum, w_of), nt, batch, wpack, stream));
+  return GUNET_OK;
+}
+
+// The same with the bias given per 32-column tile: bias_of(col) points at the 32 bias values of the
+// tile that starts at output column `col` (or is null).
+template <typename WeightOf, typename BiasOf>
+int launch_gemm_columns_tile_bias(const GemmArgs& g, int units, int64_t batch, BiasOf bias_of, float* out,
+                                  WeightOf w_of, void* wpack, hipStream_t stream) {
+  const int nt = columns_nt(g);
+  for (int col0 = 0; col0 < units; col0 += 32 * nt) {
+    GemmArgs gc = columns_block(g, units, col0, nt, nullptr, 0, out, nullptr, w_of);
+    gc.bias_by_tile = 1;
+    for (int t = 0; t < nt; ++t) gc.bias_tile[t] = bias_of(col0 + 32 * t);
+    GUNET_TRY(launch_gemm(gc, nt, batch, wpack, stream));
+  }
   return GUNET_OK;
 }
 

@@ -62,7 +62,10 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
   double csd[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * (ct + n) + li] : 0.0f;
+    if (g.bias_by_tile)
+      bias_v[n] = g.bias_tile[ct + n] ? g.bias_tile[ct + n][li] : 0.0f;
+    else
+      bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * (ct + n) + li] : 0.0f;
     csd[n] = 0.0;
   }
 
@@ -406,7 +409,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   double cs[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + 32 * n + li] : 0.0f;
+    if (g.bias_by_tile)
+      bias_v[n] = g.bias_tile[n] ? g.bias_tile[n][li] : 0.0f;
+    else
+      bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + 32 * n + li] : 0.0f;
     cs[n] = 0.0;
   }
   const bool want_cs = g.colsum != nullptr;
@@ -728,7 +734,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_split(GemmArgs g, const ui
   float bias_v[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * n + li] : 0.0f;
+    if (g.bias_by_tile)
+      bias_v[n] = g.bias_tile[n] ? g.bias_tile[n][li] : 0.0f;
+    else
+      bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * n + li] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
   }
