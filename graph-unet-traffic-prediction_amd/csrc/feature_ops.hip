@@ -848,8 +848,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Which form of the edge kernel a layer on `g` with `batch` samples takes, and how many partial
-// rows per direction it therefore writes: 8 groups per wave unless that leaves fewer than two
-// workgroups per compute unit.
+// rows per direction it therefore writes: 8 groups per wave unless that leaves more than half of
+// the compute units without a workgroup (below that the shorter dependent chain of the 2-group form
+// outweighs the four times as many copies of the weights into LDS; measured crossover).
 struct EdgeSplit {
   int eg, n_eblk;
 };
@@ -859,7 +860,7 @@ EdgeSplit edge_split(const gunet_quadgraph* g, int64_t batch) {
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
   const int64_t large = ceil_div(max_e, edges_per_block(kEdgeGroupsLarge));
   EdgeSplit sp;
-  sp.eg = large * 4 * batch < 2 * static_cast<int64_t>(device_cu_count()) ? kEdgeGroupsSmall : kEdgeGroupsLarge;
+  sp.eg = 2 * large * 4 * batch < static_cast<int64_t>(device_cu_count()) ? kEdgeGroupsSmall : kEdgeGroupsLarge;
   sp.n_eblk = static_cast<int>(ceil_div(max_e, edges_per_block(sp.eg)));
   return sp;
 }

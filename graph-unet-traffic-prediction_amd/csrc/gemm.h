@@ -25,6 +25,9 @@ struct GemmArgs {
   int n_rows;                 // A rows per sample
   const float* bias;          // [.., 32*NT] or null
   int bias_stride;            // floats between samples (0 = shared)
+  int paired;                 // weights-resident kernel, 64-column form: one launch does both 64-column halves
+                              //   of a 128-column block (w[0..3] set); the two workgroups that share a row
+                              //   range sit on the same XCD, so the second read of the operands hits its L2
   const float* bias_tile[4];  // with bias_by_tile: 32 floats of bias per column tile (null = none), shared
   int bias_by_tile;           //   by all samples -- the four directions' embedding biases where they lie
   float* out;                 // sample 0; null = compute the column sums only
@@ -117,6 +120,14 @@ template <typename WeightOf>
 int launch_gemm_columns(const GemmArgs& g, int units, int64_t batch, const float* bias, int bias_stride, float* out,
                         double* colsum, WeightOf w_of, void* wpack, hipStream_t stream) {
   const int nt = columns_nt(g);
+  if (nt == 2 && units % 128 == 0) {   // the 64-column gathering form: both halves of a 128-column block per launch
+    for (int col0 = 0; col0 < units; col0 += 128) {
+      GemmArgs gc = columns_block(g, units, col0, 4, bias, bias_stride, out, colsum, w_of);
+      gc.paired = 1;
+      GUNET_TRY(launch_gemm(gc, 2, batch, wpack, stream));
+    }
+    return GUNET_OK;
+  }
   for (int col0 = 0; col0 < units; col0 += 32 * nt)
     GUNET_TRY(launch_gemm(columns_block(g, units, col0, nt, bias, bias_stride, out, colsum, w_of), nt, batch, wpack, stream));
   return GUNET_OK;

@@ -279,13 +279,29 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   const int li = lane & 31, lh = lane >> 5;
   const int t0 = g.seg[0].k / kBK, t1 = g.n_seg > 1 ? g.seg[1].k / kBK : 0;   // K tiles of segments 0, 1
 
+  // Paired launch: blocks i and i + 8 -- same XCD under the round-robin dispatch -- take the two
+  // 32*NT-column halves of the same rows (when the pair count is no multiple of 8, the halves are
+  // simply the two halves of the grid).
+  int block = blockIdx.x, half = 0;
+  if (g.paired) {
+    const int pairs = gridDim.x >> 1;
+    if ((pairs & 7) == 0) {
+      half = (block >> 3) & 1;
+      block = ((block >> 4) << 3) | (block & 7);
+    } else {
+      half = block >= pairs;
+      block -= half * pairs;
+    }
+  }
+  const int col_shift = BN * half;
+
   {
     int kbase = 0;
     for (int s = 0; s < g.n_seg; ++s) {
       const GemmSeg& sg = g.seg[s];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float* w = sg.w[t];
+        const float* w = (NT == 2 && half) ? sg.w[2 + t] : sg.w[t];
         if constexpr (BF16) {
           // thread -> (group of 8 k rows, column): 8 strided loads, one 16-byte LDS store
           uint4* img = reinterpret_cast<uint4*>(Ws);
@@ -318,8 +334,8 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   }
   __syncthreads();
 
-  const int b = blockIdx.x / bps;
-  const int blk = blockIdx.x - b * bps;
+  const int b = block / bps;
+  const int blk = block - b * bps;
   int grp = (blk * kWaves + wave) * gpw;
   const int grp_end = min(grp + gpw, groups_per_sample);
   const bool has_work = grp < grp_end;   // the last workgroup of a sample may have idle waves
@@ -412,7 +428,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     if (g.bias_by_tile)
       bias_v[n] = g.bias_tile[n] ? g.bias_tile[n][li] : 0.0f;
     else
-      bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + 32 * n + li] : 0.0f;
+      bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + col_shift + 32 * n + li] : 0.0f;
     cs[n] = 0.0;
   }
   const bool want_cs = g.colsum != nullptr;
@@ -421,7 +437,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     // this lane's first pick-up row as a 32-bit byte offset; the steps between rows are uniform
     const uint32_t voff =
         ((static_cast<uint32_t>(b) * static_cast<uint32_t>(g.out_rows) + static_cast<uint32_t>(row0 + srow)) * ldo +
-         static_cast<uint32_t>(g.out_col0 + scol)) * 4u;
+         static_cast<uint32_t>(g.out_col0 + col_shift + scol)) * 4u;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       float gs = 0.0f;   // this lane's 16 rows of column 32n + li
@@ -576,7 +592,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     if (tid < BN) {
       double s = red[tid];
       for (int w = 1; w < kWaves; ++w) s += red[w * 256 + tid];
-      g.colsum[(static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + blk) * g.colsum_ld + g.out_col0 + tid] = s;
+      g.colsum[(static_cast<int64_t>(b) * g.colsum_tiles + g.colsum_tile0 + blk) * g.colsum_ld + g.out_col0 + col_shift + tid] = s;
     }
   }
 }
@@ -1020,7 +1036,7 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   }
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
-  const int blocks = static_cast<int>(batch * sp.bps);
+  const int blocks = static_cast<int>(batch * sp.bps) * (g.paired ? 2 : 1);
   k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.bps, sp.gpw);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
@@ -1064,8 +1080,9 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
     }
   }
   const bool resident = resident_ok(g, nt, batch), split = !resident && takes_split(wpack);
+  GUNET_REQUIRE(!g.paired || (resident && nt == 2), "launch_gemm: the paired form belongs to the weights-resident kernel");
   double flops = 0.0;
-  for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
+  for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt * (g.paired ? 2 : 1));
   const int kt_all = gemm_ktiles(g);
   ProfScope prof(split ? kProfGemmSplit
                        : (!resident ? kProfGemmTiled
