@@ -845,6 +845,114 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
   prologue_compute<UTN, true>(pn, gl, relu, b, part, gq, ebias, gbias, pre);
 }
 
+// ---------------------------------------------------------------- layers wider than 256 units
+//
+// GraphUNet(units >= 128) builds 512- and 1024-wide blocks (models/graph_unet.py:39-55).  They take
+// plain forms of the per-sample kernels (one thread per output column, k walked in order) and the
+// generic GEMM for the edge MLP; the tuned kernels above serve the shipped 128 / 256 widths.
+
+// Per sample: gbias = global . W_node[c_in + U .., :] + b; the chained global transforms; ebias of
+// direction q = chain_q . W_edge_q[f_e + 2u .., :] + b (see k_layer_prologue).
+__global__ __launch_bounds__(kSmallThreads) void k_layer_prologue_wide(LayerPtrs p, int U,
+                                                                       const float* __restrict__ global_in, int relu,
+                                                                       float* __restrict__ ebias,
+                                                                       float* __restrict__ gbias) {
+  extern __shared__ __attribute__((aligned(16))) float wsh[];
+  const int u = U / 4;
+  float* gl = wsh;          // [g]
+  float* gq = gl + p.g;     // [4][u]
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < p.g; k += blockDim.x) gl[k] = global_in[b * p.g + k];
+  __syncthreads();
+  for (int c = tid; c < U; c += blockDim.x) {
+    const float* w = p.node_w + static_cast<int64_t>(p.c_in + U) * U + c;
+    float s = 0.0f;
+    for (int k = 0; k < p.g; ++k) s = fmaf(gl[k], w[static_cast<int64_t>(k) * U], s);
+    if (p.node_b) s += p.node_b[c];
+    gbias[b * U + c] = s;
+  }
+  for (int q = 0; q < 4; ++q) {
+    const float* src = q == 0 ? gl : gq + (q - 1) * u;
+    const int kin = q == 0 ? p.g : u;
+    for (int j = tid; j < u; j += blockDim.x) {
+      float s = 0.0f;
+      for (int k = 0; k < kin; ++k) s = fmaf(src[k], p.glob_w[q][k * u + j], s);
+      if (p.glob_b[q]) s += p.glob_b[q][j];
+      gq[q * u + j] = activate(s, relu);
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < U; c += blockDim.x) {
+    const int q = c / u, j = c % u;
+    const float* w = p.edge_w[q] + static_cast<int64_t>(p.f_e + 2 * u) * u + j;
+    float s = 0.0f;
+    for (int k = 0; k < u; ++k) s = fmaf(gq[q * u + k], w[k * u], s);
+    if (p.edge_b[q]) s += p.edge_b[q][j];
+    ebias[b * U + c] = s;
+  }
+}
+
+// Per sample: node / edge column sums from the float64 partials, scales, glob_transform or identity
+// (see global_update_body).
+__global__ __launch_bounds__(kSmallThreads) void k_global_update_wide(LayerPtrs p, int U,
+                                                                      const float* __restrict__ global_in,
+                                                                      const double* __restrict__ npart, int n_nblk,
+                                                                      const double* __restrict__ epart, int n_eblk,
+                                                                      int relu, float* __restrict__ global_out) {
+  extern __shared__ __attribute__((aligned(16))) float wsh[];
+  const int u = U / 4;
+  float* gin = wsh;   // [g + U + u]
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < p.g; k += blockDim.x) gin[k] = global_in[b * p.g + k];
+  for (int c = tid; c < U; c += blockDim.x) {
+    const double* src = npart + b * n_nblk * static_cast<int64_t>(U) + c;
+    double s = 0.0;
+    for (int i = 0; i < n_nblk; ++i) s += src[static_cast<int64_t>(i) * U];
+    gin[p.g + c] = (static_cast<float>(s) * 1.0f) / (p.gsn * 300.0f * 300.0f);
+  }
+  for (int j = tid; j < u; j += blockDim.x) {
+    float total = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+      const double* src = epart + (b * 4 + q) * n_eblk * static_cast<int64_t>(u) + j;
+      double s = 0.0;
+      for (int i = 0; i < n_eblk; ++i) s += src[static_cast<int64_t>(i) * u];
+      total += static_cast<float>(s);
+    }
+    gin[p.g + U + j] = (total * 1.0f) / (p.gse * 300.0f * 300.0f * 8.0f);
+  }
+  __syncthreads();
+  const int kin = p.g + U + u;
+  if (p.globt_w != nullptr) {
+    for (int c = tid; c < U; c += blockDim.x) {
+      float s = 0.0f;
+      for (int k = 0; k < kin; ++k) s = fmaf(gin[k], p.globt_w[static_cast<int64_t>(k) * U + c], s);
+      if (p.globt_b) s += p.globt_b[c];
+      global_out[b * U + c] = activate(s, relu);
+    }
+  } else {
+    for (int k = tid; k < kin; k += blockDim.x) global_out[b * kin + k] = gin[k];
+  }
+}
+
+// out[r, 0..wp) = [in[r, 0..w) | zeros]: rows of a width the float4 loaders cannot take, padded to one they can
+__global__ void k_pad_rows(const float* __restrict__ in, int w, int64_t rows, int wp, float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= rows * wp) return;
+  const int64_t r = i / wp;
+  const int c = static_cast<int>(i % wp);
+  out[i] = c < w ? in[r * w + c] : 0.0f;
+}
+
+// out[b, :] = [first[b, :w0] | second[b, :w1]]
+__global__ void k_concat_rows(const float* __restrict__ first, int w0, const float* __restrict__ second, int w1,
+                              float* __restrict__ out) {
+  const int64_t b = blockIdx.x;
+  for (int k = threadIdx.x; k < w0 + w1; k += blockDim.x)
+    out[b * (w0 + w1) + k] = k < w0 ? first[b * w0 + k] : second[b * w1 + (k - w0)];
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Which form of the edge kernel a layer on `g` with `batch` samples takes, and how many partial
@@ -852,12 +960,32 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the compute units without a workgroup (below that the shorter dependent chain of the 2-group form
 // outweighs the four times as many copies of the weights into LDS; measured crossover).
 struct EdgeSplit {
-  int eg, n_eblk;
+  int eg, n_eblk;   // eg = 0: the generic GEMM form (wide layers)
 };
 
-EdgeSplit edge_split(const gunet_quadgraph* g, int64_t batch) {
+// Layers the tuned edge kernel does not serve: more than 64 columns per direction (its weights would
+// not fit LDS) or more than 64 edge features.
+inline bool edge_is_generic(const gunet_gn_weights* w) { return w->units > 256 || w->f_e > 64; }
+
+// Column-sum partial rows per sample the tiled GEMM writes for a problem of n_rows rows.
+inline int tiled_colsum_rows(int n_rows, int64_t batch) {
+  GemmArgs probe = {};
+  probe.n_rows = n_rows;
+  probe.n_seg = 1;
+  probe.seg[0].k = 4;   // never a whole K tile: the weights-resident kernels do not apply
+  double dummy = 0.0;
+  probe.colsum = &dummy;
+  return gemm_colsum_rows(probe, 1, batch, nullptr);
+}
+
+EdgeSplit edge_split(const gunet_quadgraph* g, const gunet_gn_weights* w, int64_t batch) {
   int max_e = 1;
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
+  if (edge_is_generic(w)) {   // one GEMM per direction; the reader adds the same number of rows of each
+    int rows = 1;
+    for (int q = 0; q < 4; ++q) rows = std::max(rows, g->n_edges[q] > 0 ? tiled_colsum_rows(g->n_edges[q], batch) : 0);
+    return {0, rows};
+  }
   const int64_t large = ceil_div(max_e, edges_per_block(kEdgeGroupsLarge));
   EdgeSplit sp;
   sp.eg = 2 * large * 4 * batch < static_cast<int64_t>(device_cu_count()) ? kEdgeGroupsSmall : kEdgeGroupsLarge;
@@ -886,7 +1014,7 @@ LayerWorkspace carve_workspace(const gunet_quadgraph* g, int32_t batch, int unit
   int max_e = 0;
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
   ws.n_nblk = static_cast<int>(ceil_div(g->n_nodes, kRowGroup));
-  ws.n_eblk_cap = static_cast<int>(ceil_div(max_e > 0 ? max_e : 1, edges_per_block(kEdgeGroupsSmall)));
+  ws.n_eblk_cap = static_cast<int>(ceil_div(max_e > 0 ? max_e : 1, kBM)) + 1;   // the generic form: one row per 128 edges at most
   size_t off = 0;
   auto take = [&](size_t floats) {
     float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
@@ -912,15 +1040,15 @@ int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_g
   GUNET_REQUIRE(batch > 0, "%s: batch must be positive", fn);
   GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU, "%s: unknown activation %d",
                 fn, activation);
-  if (w->units != 128 && w->units != 256) {
-    set_error("%s: units = %d is not implemented (128 and 256 are)", fn, w->units);
+  if (w->units != 128 && w->units != 256 && w->units != 512 && w->units != 1024) {
+    set_error("%s: units = %d is not implemented (128, 256, 512 and 1024 are)", fn, w->units);
     return GUNET_ERR_UNSUPPORTED;
   }
   GUNET_REQUIRE(w->c_in > 0 && w->c_in % 4 == 0 && w->c_in <= kMaxCin,
                 "%s: c_in = %d must be a positive multiple of 4, at most %d", fn, w->c_in, kMaxCin);
-  GUNET_REQUIRE(w->g > 0 && w->g <= 2048, "%s: global width %d outside 1..2048", fn, w->g);
-  if (w->f_e < 0 || w->f_e > 64) {
-    set_error("%s: edge feature width %d outside 0..64 is not implemented", fn, w->f_e);
+  GUNET_REQUIRE(w->g > 0 && w->g <= 4096, "%s: global width %d outside 1..4096", fn, w->g);
+  if (w->f_e < 0 || w->f_e > 256 || (w->f_e > 64 && w->f_e % 4 != 0)) {
+    set_error("%s: edge feature width %d is not implemented (0..64, or a multiple of 4 up to 256)", fn, w->f_e);
     return GUNET_ERR_UNSUPPORTED;
   }
   GUNET_REQUIRE(graph->n_nodes >= 0, "%s: negative node count", fn);
@@ -965,6 +1093,13 @@ LayerPtrs layer_ptrs(const gunet_gn_weights* w) {
 int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu, int fold_receiver,
                     int32_t batch, const LayerWorkspace& ws, hipStream_t stream) {
   ProfScope prof(kProfPrologue, stream);
+  if (ut > 2) {
+    GUNET_REQUIRE(!fold_receiver, "layer_prologue: the zero-row-free upsampling form is not implemented above 256 units");
+    k_layer_prologue_wide<<<batch, kSmallThreads, sizeof(float) * (p.g + 128 * ut), stream>>>(p, 128 * ut, global_in, relu,
+                                                                                            ws.ebias, ws.gbias);
+    GUNET_LAUNCH_CHECK();
+    return GUNET_OK;
+  }
   const size_t lds = sizeof(float) * (4096 + p.g + 4 * 32 * ut);
   if (ut == 1)
     k_layer_prologue<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, relu, fold_receiver,
@@ -979,6 +1114,12 @@ int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu
 int launch_global_update(const LayerPtrs& p, int ut, const float* global_in, int n_nblk, int n_eblk, int relu,
                          int32_t batch, const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
   ProfScope prof(kProfGlobalUpdate, stream);
+  if (ut > 2) {
+    k_global_update_wide<<<batch, kSmallThreads, sizeof(float) * (p.g + 160 * ut), stream>>>(
+        p, 128 * ut, global_in, ws.npart, n_nblk, ws.epart, n_eblk, relu, global_out);
+    GUNET_LAUNCH_CHECK();
+    return GUNET_OK;
+  }
   const size_t lds = sizeof(double) * 4096 + sizeof(float) * (4096 + p.g + 160 * ut);
   if (ut == 1)
     k_global_update<1><<<batch, kSmallThreads, lds, stream>>>(p, global_in, ws.npart, n_nblk, ws.epart,
@@ -1037,10 +1178,76 @@ int launch_edge_mlp_ut(EdgeArgs& a, int chunks, bool vec, int eg, dim3 grid, hip
                                 : launch_edge_mlp_inst<UT, kEdgeGroupsSmall>(a, chunks, vec, grid, stream);
 }
 
-int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const float* const edges[4],
-                    int32_t batch, hipStream_t stream) {
-  const EdgeSplit split = edge_split(graph, batch);
+// The edge MLP of a wide layer (hybrid_gnn.py:93-108) as four generic GEMMs, one per direction, over
+// the operand segments [edge features | embedding of the sender | embedding of the receiver], the
+// last two gathered through the edge list; bias = the folded global term; column sums into epart.
+int launch_edge_generic(const EdgeArgs& a, const gunet_gn_weights* w, const gunet_quadgraph* graph,
+                        const float* const edges[4], int n_eblk, int32_t batch, void* wpack, float* pad_scratch,
+                        hipStream_t stream) {
+  const int U = w->units, u = U / 4;
+  GUNET_REQUIRE(!a.sender_only, "edge_mlp: the sender-only form is not implemented above 256 units");
+  // quadrants write different numbers of partial rows; the reader adds n_eblk of each
+  GUNET_HIP_TRY(hipMemsetAsync(a.partial, 0, sizeof(double) * batch * 4 * n_eblk * u, stream));
+  for (int q = 0; q < 4; ++q) {
+    if (graph->n_edges[q] == 0) continue;
+    GemmArgs g = {};
+    int row_of[3], s = 0;
+    if (w->f_e > 0 && edges != nullptr && edges[q] != nullptr) {
+      g.seg[s].a = edges[q];
+      g.seg[s].lda = w->f_e;
+      if (w->f_e % 4 != 0 || reinterpret_cast<uintptr_t>(edges[q]) % 16 != 0) {
+        // a width the float4 loads cannot take (the 2 zero columns of the upsampling layer): a
+        // zero-padded copy; the weight rows past f_e are zero in LDS, k stays f_e
+        const int wp = (w->f_e + 3) / 4 * 4;
+        const int64_t rows = static_cast<int64_t>(batch) * graph->n_edges[q];
+        GUNET_REQUIRE(rows * wp <= static_cast<int64_t>(batch) * a.n_nodes * U, "edge_mlp: no room to pad %lld edge rows",
+                      static_cast<long long>(rows));
+        k_pad_rows<<<static_cast<unsigned>(ceil_div(rows * wp, kThreads)), kThreads, 0, stream>>>(edges[q], w->f_e, rows, wp,
+                                                                                                pad_scratch);
+        GUNET_LAUNCH_CHECK();
+        g.seg[s].a = pad_scratch;
+        g.seg[s].lda = wp;
+      }
+      g.seg[s].k = w->f_e;
+      row_of[s++] = 0;
+    }
+    for (int side = 0; side < 2; ++side) {
+      g.seg[s].a = a.xq + u * q;
+      g.seg[s].lda = U;
+      g.seg[s].k = u;
+      g.seg[s].row_idx = graph->edge_index[q] + side;
+      g.seg[s].idx_stride = 2;
+      g.seg[s].a_rows = a.n_nodes;
+      row_of[s++] = w->f_e + side * u;
+    }
+    g.n_seg = s;
+    for (int i = 0; i < s; ++i) g.seg[i].ldw = u;
+    g.n_rows = graph->n_edges[q];
+    g.relu = a.relu;
+    g.colsum_tiles = 4 * n_eblk;
+    g.colsum_tile0 = q * n_eblk;
+    GUNET_REQUIRE(gemm_colsum_rows([&] { GemmArgs t = g; double d; t.colsum = &d; return t; }(), 1, batch, nullptr) <= n_eblk,
+                  "edge_mlp: more column-sum rows than the layer planned");
+    auto w_of = [&](int seg, int col) { return w->edge_w[q] + static_cast<int64_t>(row_of[seg]) * u + col; };
+    const int nt = u >= 128 ? 4 : u / 32;
+    for (int col0 = 0; col0 < u; col0 += 32 * nt)
+      GUNET_TRY(launch_gemm(columns_block(g, u, col0, nt, a.ebias + q * u, U, a.out[q], a.partial, w_of), nt, batch, wpack,
+                            stream));
+  }
+  return GUNET_OK;
+}
+
+// pad_scratch: room for batch * max_q E_q * 4 floats (the layer's aggregate buffer, idle at this point)
+int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const gunet_gn_weights* w,
+                    const float* const edges[4], int32_t batch, void* wpack, float* pad_scratch, hipStream_t stream) {
+  const EdgeSplit split = edge_split(graph, w, batch);
   const int n_eblk = split.n_eblk;
+  if (split.eg == 0) {
+    double edges_total = 0.0;
+    for (int q = 0; q < 4; ++q) edges_total += graph->n_edges[q];
+    ProfScope prof(kProfEdgeMlp, stream, 2.0 * batch * edges_total * (w->f_e + 2.0 * (w->units / 4)) * (w->units / 4));
+    return launch_edge_generic(a, w, graph, edges, n_eblk, batch, wpack, pad_scratch, stream);
+  }
   bool any_feat = false, all_feat = true, vec_ok = a.f_e % 8 == 0;
   for (int q = 0; q < 4; ++q) {
     a.edge_index[q] = graph->edge_index[q];
@@ -1163,7 +1370,7 @@ int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const 
 }
 
 size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batch, int32_t units) {
-  if (graph == nullptr || batch <= 0 || (units != 128 && units != 256)) return 0;
+  if (graph == nullptr || batch <= 0 || (units != 128 && units != 256 && units != 512 && units != 1024)) return 0;
   return carve_workspace(graph, batch, units, nullptr).bytes;
 }
 
@@ -1247,7 +1454,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     a.partial = ws.epart;
     a.relu = relu;
     a.out_scale = 1.0f;
-    GUNET_TRY(launch_edge_mlp(a, ut, graph, edges, batch, stream));
+    GUNET_TRY(launch_edge_mlp(a, ut, graph, w, edges, batch, ws.wpack, ws.agg, stream));
   }
 
   // node MLP over [x | x_skip | aggregated messages]; global columns folded into the bias (:118-126)
@@ -1310,10 +1517,12 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     double edges_total = 0.0;
     for (int q = 0; q < 4; ++q) edges_total += graph->n_edges[q];
     ProfScope prof(kProfAggregate, stream, 4.0 * batch * (edges_total * u + edges_total + static_cast<double>(n) * U));
-    if (ut == 1)
-      k_aggregate<1><<<grid, kThreads, 0, stream>>>(a);
-    else
-      k_aggregate<2><<<grid, kThreads, 0, stream>>>(a);
+    switch (ut) {
+      case 1: k_aggregate<1><<<grid, kThreads, 0, stream>>>(a); break;
+      case 2: k_aggregate<2><<<grid, kThreads, 0, stream>>>(a); break;
+      case 4: k_aggregate<4><<<grid, kThreads, 0, stream>>>(a); break;
+      default: k_aggregate<8><<<grid, kThreads, 0, stream>>>(a); break;
+    }
     GUNET_LAUNCH_CHECK();
   }
 
@@ -1324,7 +1533,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
 
   if (n_partials_out) *n_partials_out = n_partials;
   if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-  return launch_global_update(p, ut, global_in, n_partials, edge_split(graph, batch).n_eblk, relu, batch, ws, global_out,
+  return launch_global_update(p, ut, global_in, n_partials, edge_split(graph, w, batch).n_eblk, relu, batch, ws, global_out,
                               stream);
 }
 
@@ -1345,6 +1554,11 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
                 static_cast<long long>(n_edges), n_fine);
   GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0,
                 "gn_upsample: x and x_out must be 16-byte aligned");
+  if (w->units > 256) {
+    set_error("gn_upsample: the zero-row-free form is implemented for 128 and 256 units; run the layer on [x ; 0] "
+              "(gunet_gn_layer_forward_f32 on the upsampling graph) for %d", w->units);
+    return GUNET_ERR_UNSUPPORTED;
+  }
   const int relu = activation == GUNET_ACT_RELU;
   const int U = w->units, u = U / 4, ut = U / 128;
   const LayerPtrs p = layer_ptrs(w);
@@ -1387,7 +1601,7 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
     a.relu = relu;
     a.sender_only = 1;
     a.out_scale = 1.0f / (3 + 1);
-    GUNET_TRY(launch_edge_mlp(a, ut, graph, nullptr, batch, stream));
+    GUNET_TRY(launch_edge_mlp(a, ut, graph, w, nullptr, batch, ws.wpack, ws.agg, stream));
   }
 
   // node MLP.  Coarse rows: only the x columns are non-zero and only their column sums are used
@@ -1438,7 +1652,7 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
   }
   if (n_partials_out) *n_partials_out = tiles_total;
   if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-  return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, batch).n_eblk, relu, batch, ws, global_out,
+  return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, w, batch).n_eblk, relu, batch, ws, global_out,
                               stream);
 }
 
@@ -1457,11 +1671,23 @@ int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int
   GUNET_REQUIRE(n_partials >= 0 && n_partials <= wc.n_nblk + 5, "gn_bridge: %d column-sum rows", n_partials);
   const LayerPtrs pc = layer_ptrs(cur), pn = layer_ptrs(next);
   const int utc = cur->units / 128, utn = next->units / 128;
+  if (utc > 2 || utn > 2) {   // a wide layer on either side: its own kernels, one after the other
+    const int relu_ = activation == GUNET_ACT_RELU;
+    GUNET_TRY(launch_global_update(pc, utc, global_in, n_partials, edge_split(cur_graph, cur, batch).n_eblk, relu_, batch,
+                                   wc, global_out, stream));
+    const float* next_in = global_out;
+    if (extra != nullptr) {
+      k_concat_rows<<<batch, 256, 0, stream>>>(global_out, g_new, extra, extra_width, cat_out);
+      GUNET_LAUNCH_CHECK();
+      next_in = cat_out;
+    }
+    return launch_prologue(pn, utn, next_in, relu_, next_fold_receiver, batch, wn, stream);
+  }
   const size_t lds = sizeof(double) * 4096 + sizeof(float) * (4096 + pc.g + 160 * utc + pn.g + 4 * 32 * utn);
   GUNET_REQUIRE(lds <= 64 * 1024, "gn_bridge: global vectors of %d and %d floats do not fit", pc.g, pn.g);
   const int relu = activation == GUNET_ACT_RELU;
   ProfScope prof(kProfBridge, stream);
-  const int n_eblk = edge_split(cur_graph, batch).n_eblk;
+  const int n_eblk = edge_split(cur_graph, cur, batch).n_eblk;
   return utc == 1 ? launch_bridge_utc<1>(pc, pn, utn, lds, batch, global_in, n_partials, n_eblk, wc, relu, global_out,
                                          extra, extra_width, cat_out, next_fold_receiver, wn, stream)
                   : launch_bridge_utc<2>(pc, pn, utn, lds, batch, global_in, n_partials, n_eblk, wc, relu, global_out,

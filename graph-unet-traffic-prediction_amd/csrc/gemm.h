@@ -17,6 +17,11 @@ struct GemmSeg {
   int k;               // width of this segment (multiple of 4)
   const float* w[4];   // weights of column tile t: element [k][j] at w[t][k * ldw + j], j < 32
   int ldw;
+  // Gathered segment (tiled float32 kernel only): row r of the operand is row
+  // row_idx[r * idx_stride] of `a`, a [B][a_rows][lda] tensor (null = row r itself)
+  const int32_t* row_idx;
+  int idx_stride;
+  int a_rows;
 };
 
 struct GemmArgs {
@@ -59,8 +64,8 @@ constexpr int kBM = 128;
 constexpr int kBK = 32;
 constexpr int kRowGroup = 32;   // rows of one wave = rows of one column-sum partial
 
-constexpr int kMaxCin = 1024;    // widest layer input the workspaces are sized for
-constexpr int kMaxUT = 2;        // widest layer: 128 * kMaxUT columns
+constexpr int kMaxCin = 2048;    // widest layer input the workspaces are sized for
+constexpr int kMaxUT = 8;        // widest layer: 128 * kMaxUT columns
 
 inline int gemm_ktiles(const GemmArgs& g) {
   int n = 0;

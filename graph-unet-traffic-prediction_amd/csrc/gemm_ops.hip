@@ -77,11 +77,19 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
     const bool row_ok = my_row < g.n_rows;
 
     float4 b_reg[NT];
+    // this lane's operand row in each segment (a gathered segment looks it up once per row tile)
+    int64_t a_row[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      a_row[s] = b * g.n_rows + my_row;
+      if (s < g.n_seg && g.seg[s].row_idx != nullptr)
+        a_row[s] = b * g.seg[s].a_rows + (row_ok ? g.seg[s].row_idx[static_cast<int64_t>(my_row) * g.seg[s].idx_stride] : 0);
+    }
     auto load_a = [&](int t, float4 (&a)[4]) {
       int s, k0;
       locate(t, s, k0);
       const GemmSeg& sg = g.seg[s];
-      const float* p = sg.a + (b * g.n_rows + my_row) * static_cast<int64_t>(sg.lda) + k0 + 4 * lh;
+      const float* p = sg.a + (s == 0 ? a_row[0] : (s == 1 ? a_row[1] : a_row[2])) * static_cast<int64_t>(sg.lda) + k0 + 4 * lh;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (row_ok && k0 + 8 * c + 4 * lh < sg.k)
@@ -906,8 +914,14 @@ inline bool resident_ragged(const GemmArgs& g) {
          g.seg[0].k > 3 * kBK && g.seg[0].k < 4 * kBK;
 }
 
+inline bool gathers_rows(const GemmArgs& g) {
+  for (int s = 0; s < g.n_seg; ++s)
+    if (g.seg[s].row_idx != nullptr) return true;
+  return false;
+}
+
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
-  if (g.row_map != nullptr) return false;
+  if (g.row_map != nullptr || gathers_rows(g)) return false;
   if (mode_pieces(g_matmul_mode) > 1) return false;   // split-bf16 modes: tiled kernel only
   const bool bf16 = bf16_mode();
   const bool ragged = resident_ragged(g);   // one float32 segment of 97..127 columns, 128 output columns
@@ -988,7 +1002,7 @@ int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack
   if (g.n_rows == 0) return 0;
   if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, resident_block_waves(g, nt)).bps;
   const int64_t tiles = ceil_div(g.n_rows, kBM);
-  if (takes_split(wpack)) return static_cast<int>(tiles);
+  if (takes_split(wpack) && !gathers_rows(g)) return static_cast<int>(tiles);
   return static_cast<int>(ceil_div(tiles, tiled_tiles_per_wg(g, batch, true)));
 }
 
@@ -1079,7 +1093,7 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
       return GUNET_ERR_INVALID;
     }
   }
-  const bool resident = resident_ok(g, nt, batch), split = !resident && takes_split(wpack);
+  const bool resident = resident_ok(g, nt, batch), split = !resident && takes_split(wpack) && !gathers_rows(g);
   GUNET_REQUIRE(!g.paired || (resident && nt == 2), "launch_gemm: the paired form belongs to the weights-resident kernel");
   double flops = 0.0;
   for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt * (g.paired ? 2 : 1));

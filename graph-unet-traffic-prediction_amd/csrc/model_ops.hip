@@ -236,8 +236,8 @@ int carve_model(const char* who, const gunet_plan* P, const gunet_unet_weights* 
   size_t layer_ws = 0;
   auto check = [&](const char* name, int idx, const gunet_gn_weights& g, int c_in, int f_e, int gw,
                    const gunet_quadgraph& graph) -> int {
-    GUNET_REQUIRE(g.units == 128 || g.units == 256, "%s: %s[%d] is %d wide (128 and 256 are implemented)", who, name,
-                  idx, g.units);
+    GUNET_REQUIRE(g.units == 128 || g.units == 256 || g.units == 512 || g.units == 1024,
+                  "%s: %s[%d] is %d wide (128, 256, 512 and 1024 are implemented)", who, name, idx, g.units);
     GUNET_REQUIRE(g.c_in == c_in && g.f_e == f_e && g.g == gw,
                   "%s: %s[%d] has c_in, f_e, g = %d, %d, %d; the layers before it give %d, %d, %d", who, name, idx,
                   g.c_in, g.f_e, g.g, c_in, f_e, gw);
@@ -294,9 +294,9 @@ int carve_model(const char* who, const gunet_plan* P, const gunet_unet_weights* 
       mb->skip_e[l].q[q] = l > 0 ? cv.take(batch * L.n_edges[q] * we[l]) : nullptr;
     }
   }
-  int64_t literal_rows = 0;   // upsampling levels without the one-edge-per-fine-node structure
+  int64_t literal_rows = 0;   // upsampling levels that run the layer on [x ; 0] as the reference writes it
   for (int l = 0; l < D; ++l) {
-    if (P->one_parent_edge[l]) continue;
+    if (P->one_parent_edge[l] && w->up_sampling[D - 1 - l].units <= 256) continue;
     const gunet_plan::Level& U = P->ups[l];
     literal_rows = U.n_nodes > literal_rows ? U.n_nodes : literal_rows;
     for (int q = 0; q < 4; ++q) max_edges[q] = U.n_edges[q] > max_edges[q] ? U.n_edges[q] : max_edges[q];
@@ -618,7 +618,7 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
     const int target_width = l == 0 ? w->down[0].g : global_out_width(w->down[l - 1]);
     float* g_cat = next_global();   // [global | target global], hybrid_gnn.py:375
     float* g_up = next_global();
-    const bool fast = P->one_parent_edge[l];
+    const bool fast = P->one_parent_edge[l] && up.units <= 256;   // else the reference's literal route
     GUNET_TRY(enter(&P->ups[l].qg, &up, fast ? 1 : 0, target_g, target_width, g_cat));
     pend = {&P->ups[l].qg, &up, 0, g_cat, g_up};
     if (fast) {

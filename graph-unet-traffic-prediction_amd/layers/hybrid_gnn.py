@@ -419,7 +419,8 @@ class GraphUpsampling2x2:
         glob = torch.cat((graph['global'].reshape(-1, graph['global'].shape[-1]),
                           target_graph['global'].reshape(-1, target_graph['global'].shape[-1])),
                          dim=-1)                                            # :375
-        if isinstance(self.gcn, GeoQuadrantGCN) and sum(int(e.shape[0]) for e in up.edge_index) == up.n_fine:
+        if (isinstance(self.gcn, GeoQuadrantGCN) and self.gcn.units <= 256
+                and sum(int(e.shape[0]) for e in up.edge_index) == up.n_fine):
             # same result as the layer on [x ; zeros] with zero edge features (:342-377), without
             # computing the zero rows
             x, graph['global'] = self.gcn._upsample_forward(x, glob, up)

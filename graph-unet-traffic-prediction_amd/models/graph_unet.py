@@ -19,8 +19,9 @@ class GraphUNet(GraphBaseModel):
 
     The reference floors every block width at 128 and builds both bottleneck layers 128 wide
     (models/graph_unet.py:37,40,46-49,53); `min_units` (keyword-only, not in the reference) replaces
-    that 128, so GraphUNet(64, min_units=256) is 256 wide throughout.  Block widths of 128 and 256
-    are implemented."""
+    that 128, so GraphUNet(64, min_units=256) is 256 wide throughout.  Block widths of 128, 256, 512
+    and 1024 are implemented (GraphUNet(128, depth=3) builds 128 / 256 / 512, GraphUNet(256, depth=3)
+    256 / 512 / 1024); the tuned kernels serve 128 and 256, wider blocks take generic ones."""
 
     def __init__(self, units, out_units=8, depth=5, activation=None, layer_type=None, use_bias=False,
                  use_global=False, output_activation=None, *, min_units=128, **layer_args):

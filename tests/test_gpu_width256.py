@@ -84,7 +84,7 @@ def test_graph_upsampling_layer_256(amd, oracle):
 @pytest.mark.parametrize('units,depth', [(64, 3), (128, 2)])
 def test_graph_unet_wide(amd, oracle, units, depth):
     """units=64, depth 3: blocks of width 128,128,256 / 128,128 / 256,128,128; units=128, depth 2:
-    128,256 / 128,128 / 256,128 (wider blocks than 256 are not implemented)."""
+    128,256 / 128,128 / 256,128."""
     x, graph, _ = make_case(oracle, 40, 52, 0.45)
     W = oracle.make_weights(oracle.graph_unet_shapes_for(units, depth=depth), 7)
     want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W, depth=depth)
@@ -111,8 +111,60 @@ def test_graph_unet_uniform_256(amd, oracle):
     assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
 
 
+@pytest.mark.parametrize('units,c_in,f_e,g', [(512, 256, 64, 256), (1024, 512, 128, 512), (128, 512, 128, 512)])
+def test_gn_layer_wide(amd, oracle, units, c_in, f_e, g):
+    """512- and 1024-wide layers (generic kernels), and the 128-wide bottleneck layer that follows a
+    512-wide block (512 input columns, 128 edge features: its edge MLP takes the generic form too)."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(29, 35, 0.55, 23)
+    quads = oracle.sample_quadrant_subgraphs(ei, d)
+    rng = np.random.Generator(np.random.PCG64(24))
+    n = node_loc.shape[0]
+    x = (rng.random((n, c_in)) - 0.2).astype(np.float32)
+    graph = {'edge_index': list(quads), 'node_loc': node_loc,
+             'edges': [(rng.random((q.shape[0], f_e)) - 0.3).astype(np.float32) for q in quads],
+             'global': rng.random((1, g)).astype(np.float32)}
+    W = oracle.make_weights(oracle.gn_layer_shapes('L', c_in, f_e, g, units), 4)
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
+    layer = amd.hybrid_gnn.GeoQuadrantGCN(units, activation='relu', use_bias=True, use_global=True)
+    layer.load_weights(W, 'L', 'cuda')
+    got_x, got_g = layer(to_dev(x), graph_to_dev(graph))
+    assert tuple(got_x.shape) == (n, units)
+    assert_close(got_x.cpu().numpy(), want_x, TOL)
+    for q in range(4):
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
+    gb = graph_to_dev(graph)                                   # batch of 3: rows equal the single call
+    gb['edges'] = [e.unsqueeze(0).repeat(3, 1, 1) for e in gb['edges']]
+    gb['global'] = gb['global'].repeat(3, 1)
+    bx, bg = layer(to_dev(x).unsqueeze(0).repeat(3, 1, 1), gb)
+    for b in range(3):
+        assert torch.equal(bx[b], got_x) and torch.equal(bg['global'][b], got_g['global'][0])
+
+
+@pytest.mark.parametrize('units', [128, 256])
+def test_graph_unet_reference_width_schedule(amd, oracle, units):
+    """The reference constructor's widths for units >= 128 at depth 3 (models/graph_unet.py:37-55):
+    units=128 -> blocks 128, 256, 512 / 128, 128 / 512, 256, 128; units=256 -> 256, 512, 1024 / 128, 128 /
+    1024, 512, 256.  One-call forward against the oracle, and against the layer-by-layer path."""
+    x, graph, _ = make_case(oracle, 40, 52, 0.45)
+    shapes = oracle.graph_unet_shapes_for(units)
+    assert shapes['downsampling_layers/2/gcns/0/node_transform/kernel'][1] == 4 * units
+    W = oracle.make_weights(shapes, 7)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    model = amd.GraphUNet(units, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                          use_bias=True, use_global=True, output_activation=None).load_weights(W, 'cuda')
+    got_y, got_g = model(to_dev(x), graph_to_dev(graph))
+    assert_close(got_y.cpu().numpy(), want_y, TOL)
+    assert_close(got_g['global'].cpu().numpy(), want_g['global'], TOL)
+    for q in range(4):
+        assert_close(got_g['edges'][q].cpu().numpy(), want_g['edges'][q], TOL)
+    model.native_forward = False
+    ly, lg = model(to_dev(x), graph_to_dev(graph))
+    assert torch.equal(ly, got_y) and torch.equal(lg['global'], got_g['global'])
+
+
 def test_unsupported_width(amd):
-    layer = amd.hybrid_gnn.GeoQuadrantGCN(512, activation='relu', use_bias=False, use_global=True)
+    layer = amd.hybrid_gnn.GeoQuadrantGCN(384, activation='relu', use_bias=False, use_global=True)
     x = torch.zeros((4, 128), device='cuda')
     e = [torch.zeros((0, 2), dtype=torch.int32, device='cuda')] * 4
     with pytest.raises(NotImplementedError):
