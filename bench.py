@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument('--gather', default='f32', choices=['f32', 'u8', 'none'],
                     help='N > 1: what is gathered per step -- float32 predictions, the uint8 prediction image '
                          '(submission format, 6 horizons), or nothing')
+    ap.add_argument('--expanded-edges', action='store_true',
+                    help='config 2/5: give every sample its own copy of the (city-static) input edge features')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-runs', type=int, default=7, help='timed CPU forwards (about 1.5 s each)')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel event pass')
@@ -389,7 +391,11 @@ def run_model(args, ranks):
         globs.append(torch.as_tensor(glob))
     x_dev = torch.stack(xs).to(dev)                                   # [B, N, 104]
     glob_dev = torch.cat(globs, dim=0).to(dev)                        # [B, 113]
-    edges_dev = [torch.as_tensor(e).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous() for e in edges_np]
+    # the street-map edge features depend on the city only: one [E_q, 16] tensor per direction serves the
+    # whole batch (--expanded-edges hands the library B copies instead, [B, E_q, 16])
+    edges_dev = [torch.as_tensor(e).to(dev) for e in edges_np]
+    if args.expanded_edges:
+        edges_dev = [e.unsqueeze(0).repeat(B, 1, 1).contiguous() for e in edges_dev]
     node_loc_dev = torch.as_tensor(node_loc).to(dev)
     del xs, globs
 
@@ -767,7 +773,7 @@ def run_cities(args, ranks):
         city[c] = {'n': n, 'ids': ids, 'quads': quads, 'quads_np': quads_np, 'node_loc_np': node_loc,
                    'node_loc': torch.as_tensor(node_loc).to(dev), 'x': torch.stack(xs).to(dev),
                    'glob': torch.cat(globs, dim=0).to(dev),
-                   'edges': [torch.as_tensor(e).to(dev).unsqueeze(0).repeat(b, 1, 1).contiguous() for e in edges_np],
+                   'edges': [torch.as_tensor(e).to(dev) for e in edges_np],      # [E_q, 16], shared by the city's samples
                    'target': torch.rand((b, n, 96), generator=tg, device=dev), 'first': first}
     setup_s = time.perf_counter() - t0
 

@@ -234,7 +234,7 @@ int main(int argc, char** argv) {
   for (int run = 0; run < 2; ++run) {
     HIP_OK(hipMemsetAsync(d_out, 0xff, out_count * sizeof(float), stream));
     HIP_OK(hipEventRecord(t0, stream));
-    GUNET_CALL(gunet_unet_forward_f32(plan, &w, batch, d_x, d_feat, d_glob, GUNET_ACT_RELU, GUNET_ACT_RELU, d_out, nullptr,
+    GUNET_CALL(gunet_unet_forward_f32(plan, &w, batch, d_x, d_feat, /*edges_shared=*/0, d_glob, GUNET_ACT_RELU, GUNET_ACT_RELU, d_out, nullptr,
                                       nullptr, workspace, ws_bytes, stream));
     HIP_OK(hipEventRecord(t1, stream));
     HIP_OK(hipStreamSynchronize(stream));

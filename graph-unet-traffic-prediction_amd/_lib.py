@@ -102,7 +102,7 @@ SIGNATURES = {
                                                     C.c_int32]),
     'gunet_gn_layer_forward_f32': (C.c_int, [C.POINTER(QuadGraphStruct),
                                              C.POINTER(GnWeightsStruct), C.c_int32, C.c_void_p,
-                                             C.c_void_p, C.c_int32, C.POINTER(VoidP4), C.c_void_p,
+                                             C.c_void_p, C.c_int32, C.POINTER(VoidP4), C.c_int32, C.c_void_p,
                                              C.c_int32, C.c_void_p, C.POINTER(VoidP4), C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     'gunet_gn_upsample_forward_f32': (C.c_int, [C.POINTER(QuadGraphStruct), C.c_int32,
@@ -122,10 +122,10 @@ SIGNATURES = {
                                                C.c_void_p]),
     'gunet_unet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32]),
     'gunet_unet_forward_f32': (C.c_int, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32, C.c_void_p,
-                                         C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.POINTER(VoidP4), C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                          C.POINTER(VoidP4), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'gunet_unet_forward_static_f32': (C.c_int, [C.c_void_p, C.POINTER(UNetWeightsStruct), C.c_int32, C.c_void_p,
-                                                C.POINTER(VoidP4), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                C.POINTER(VoidP4), C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                                 C.POINTER(VoidP4), C.c_void_p, C.c_void_p]),
     'gunet_street_encoding_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_void_p, C.c_void_p]),

@@ -146,6 +146,7 @@ int csr_from_keys(const int32_t* keys, int key_stride, int key_offset, int64_t n
 // global update (or gn_bridge) of that layer needs.  flags = 0 is the public entry point.
 constexpr int kGnSkipPrologue = 1;
 constexpr int kGnSkipGlobalUpdate = 2;
+constexpr int kGnEdgesShared = 4;   // edges[q] is one [E_q, f_e] tensor for all samples
 int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch, const float* x,
                  const float* x_skip, int32_t c_skip, const float* const edges[4], const float* global_in,
                  int32_t activation, float* x_out, float* const edges_out[4], float* global_out, void* workspace,

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue(LayerPtrs p,
 
 struct EdgeArgs {
   const int32_t* edge_index[4];
-  const float* efeat[4];    // [B, E_q, f_e] or null
+  const float* efeat[4];    // [B, E_q, f_e] ([E_q, f_e] with ef_shared) or null
+  int ef_shared;
   const float* edge_w[4];   // [f_e + 3u, u]
   float* out[4];            // [B, E_q, u]
   int n_edges[4];
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
     for (int t = 0; t < UT; ++t) bias[t] = a.ebias[(b * 4 + q) * u + 32 * t + li];
     const int2* ei = reinterpret_cast<const int2*>(a.edge_index[q]);
     const float* xq = a.xq + b * a.n_nodes * static_cast<int64_t>(U) + u * q;
-    const float* ef = a.efeat[q] ? a.efeat[q] + b * n_edges * static_cast<int64_t>(a.f_e) : nullptr;
+    const float* ef = a.efeat[q] ? a.efeat[q] + (a.ef_shared ? 0 : b * n_edges * static_cast<int64_t>(a.f_e)) : nullptr;
     float* out = a.out[q] + b * n_edges * static_cast<int64_t>(u);
     const int64_t wave_base = block_base + static_cast<int64_t>(wave) * EG * 32;
     auto edge_of = [&](int grp) {
@@ -1195,11 +1196,12 @@ int launch_edge_generic(const EdgeArgs& a, const gunet_gn_weights* w, const gune
     if (w->f_e > 0 && edges != nullptr && edges[q] != nullptr) {
       g.seg[s].a = edges[q];
       g.seg[s].lda = w->f_e;
+      g.seg[s].shared = a.ef_shared;
       if (w->f_e % 4 != 0 || reinterpret_cast<uintptr_t>(edges[q]) % 16 != 0) {
         // a width the float4 loads cannot take (the 2 zero columns of the upsampling layer): a
         // zero-padded copy; the weight rows past f_e are zero in LDS, k stays f_e
         const int wp = (w->f_e + 3) / 4 * 4;
-        const int64_t rows = static_cast<int64_t>(batch) * graph->n_edges[q];
+        const int64_t rows = static_cast<int64_t>(a.ef_shared ? 1 : batch) * graph->n_edges[q];
         GUNET_REQUIRE(rows * wp <= static_cast<int64_t>(batch) * a.n_nodes * U, "edge_mlp: no room to pad %lld edge rows",
                       static_cast<long long>(rows));
         k_pad_rows<<<static_cast<unsigned>(ceil_div(rows * wp, kThreads)), kThreads, 0, stream>>>(edges[q], w->f_e, rows, wp,
@@ -1376,12 +1378,12 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
 
 int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch,
                                const float* x, const float* x_skip, int32_t c_skip,
-                               const float* const edges[4], const float* global_in, int32_t activation,
-                               float* x_out, float* const edges_out[4], float* global_out,
+                               const float* const edges[4], int32_t edges_shared, const float* global_in,
+                               int32_t activation, float* x_out, float* const edges_out[4], float* global_out,
                                void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
   StreamDeviceGuard device_guard(as_stream(stream));
   return gn_layer_run(graph, w, batch, x, x_skip, c_skip, edges, global_in, activation, x_out, edges_out, global_out,
-                      workspace, workspace_bytes, 0, nullptr, as_stream(stream));
+                      workspace, workspace_bytes, edges_shared ? kGnEdgesShared : 0, nullptr, as_stream(stream));
 }
 
 int gunet_gn_upsample_forward_f32(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w,
@@ -1454,6 +1456,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     a.partial = ws.epart;
     a.relu = relu;
     a.out_scale = 1.0f;
+    a.ef_shared = (flags & kGnEdgesShared) ? 1 : 0;
     GUNET_TRY(launch_edge_mlp(a, ut, graph, w, edges, batch, ws.wpack, ws.agg, stream));
   }
 

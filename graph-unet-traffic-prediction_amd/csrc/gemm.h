@@ -22,6 +22,7 @@ struct GemmSeg {
   const int32_t* row_idx;
   int idx_stride;
   int a_rows;
+  int shared;          // tiled float32 kernel only: one [n_rows][lda] operand for all samples
 };
 
 struct GemmArgs {

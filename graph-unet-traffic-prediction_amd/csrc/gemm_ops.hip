@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
     int64_t a_row[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      a_row[s] = b * g.n_rows + my_row;
+      a_row[s] = (s < g.n_seg && g.seg[s].shared ? 0 : b * g.n_rows) + my_row;
       if (s < g.n_seg && g.seg[s].row_idx != nullptr)
         a_row[s] = b * g.seg[s].a_rows + (row_ok ? g.seg[s].row_idx[static_cast<int64_t>(my_row) * g.seg[s].idx_stride] : 0);
     }
@@ -914,9 +914,9 @@ inline bool resident_ragged(const GemmArgs& g) {
          g.seg[0].k > 3 * kBK && g.seg[0].k < 4 * kBK;
 }
 
-inline bool gathers_rows(const GemmArgs& g) {
+inline bool gathers_rows(const GemmArgs& g) {   // operand addressing only the tiled float32 kernel knows
   for (int s = 0; s < g.n_seg; ++s)
-    if (g.seg[s].row_idx != nullptr) return true;
+    if (g.seg[s].row_idx != nullptr || g.seg[s].shared) return true;
   return false;
 }
 

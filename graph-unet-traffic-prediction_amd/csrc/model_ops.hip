@@ -320,9 +320,9 @@ int carve_model(const char* who, const gunet_plan* P, const gunet_unet_weights* 
 }
 
 int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
-                 const float* const edges[4], const float* global_in, int32_t activation, int32_t out_activation,
-                 float* out, float* const edges_out[4], float* global_out, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream);
+                 const float* const edges[4], int32_t edges_shared, const float* global_in, int32_t activation,
+                 int32_t out_activation, float* out, float* const edges_out[4], float* global_out, void* workspace,
+                 size_t workspace_bytes, hipStream_t stream);
 
 // Intermediates of gunet_unet_forward_static_f32: one array per GPU, alive from the loading of the
 // code object to the end of the process, shared by every call on that GPU.  In host code the
@@ -473,18 +473,18 @@ size_t gunet_unet_workspace_bytes(const gunet_plan* plan, const gunet_unet_weigh
 }
 
 int gunet_unet_forward_f32(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
-                           const float* const edges[4], const float* global_in, int32_t activation,
-                           int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
-                           void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
+                           const float* const edges[4], int32_t edges_shared, const float* global_in,
+                           int32_t activation, int32_t out_activation, float* out, float* const edges_out[4],
+                           float* global_out, void* workspace, size_t workspace_bytes, gunet_stream_t stream) {
   StreamDeviceGuard device_guard(as_stream(stream));
-  return unet_forward(P, w, batch, x, edges, global_in, activation, out_activation, out, edges_out, global_out,
+  return unet_forward(P, w, batch, x, edges, edges_shared, global_in, activation, out_activation, out, edges_out, global_out,
                       workspace, workspace_bytes, as_stream(stream));
 }
 
 int gunet_unet_forward_static_f32(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
-                                  const float* const edges[4], const float* global_in, int32_t activation,
-                                  int32_t out_activation, float* out, float* const edges_out[4], float* global_out,
-                                  gunet_stream_t stream) {
+                                  const float* const edges[4], int32_t edges_shared, const float* global_in,
+                                  int32_t activation, int32_t out_activation, float* out, float* const edges_out[4],
+                                  float* global_out, gunet_stream_t stream) {
   StreamDeviceGuard device_guard(as_stream(stream));
   GUNET_REQUIRE(P && w, "unet_forward_static: null plan or weights");
   GUNET_REQUIRE(batch > 0, "unet_forward_static: batch %d", batch);
@@ -502,8 +502,8 @@ int gunet_unet_forward_static_f32(const gunet_plan* P, const gunet_unet_weights*
                 P->device, dev);
   void* base = nullptr;
   GUNET_TRY(static_scratch_of(dev, &base));
-  return unet_forward(P, w, batch, x, edges, global_in, activation, out_activation, out, edges_out, global_out, base,
-                      kStaticScratchBytes, as_stream(stream));
+  return unet_forward(P, w, batch, x, edges, edges_shared, global_in, activation, out_activation, out, edges_out,
+                      global_out, base, kStaticScratchBytes, as_stream(stream));
 }
 
 }  // extern "C"
@@ -512,9 +512,10 @@ namespace gunet {
 namespace {
 
 int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch, const float* x,
-                 const float* const edges[4], const float* global_in, int32_t activation, int32_t out_activation,
-                 float* out, float* const edges_out[4], float* global_out, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream) {
+                 const float* const edges[4], int32_t edges_shared, const float* global_in, int32_t activation,
+                 int32_t out_activation, float* out, float* const edges_out[4], float* global_out, void* workspace,
+                 size_t workspace_bytes, hipStream_t stream) {
+  const int shared0 = edges_shared ? kGnEdgesShared : 0;   // the caller's (level-0) edge features
   GUNET_REQUIRE(P && w, "unet_forward: null plan or weights");
   GUNET_REQUIRE(batch > 0, "unet_forward: batch %d", batch);
   GUNET_REQUIRE(x && edges && global_in && out, "unet_forward: null tensor");
@@ -567,8 +568,8 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
     if (l > 0) GUNET_TRY(enter(&L.qg, &gw, 0, nullptr, 0, nullptr));
     pend = {&L.qg, &gw, 0, cur_g, mb.skip_g[l + 1]};
     GUNET_TRY(gn_layer_run(&L.qg, &gw, batch, mb.skip_x[l], nullptr, 0, e_in, cur_g, activation, mb.tmp_x[0],
-                           mb.tmp_e[0].q, nullptr, mb.layer_ws, mb.layer_ws_bytes, l == 0 ? kGnSkipGlobalUpdate : mid,
-                           &pend.n_partials, stream));
+                           mb.tmp_e[0].q, nullptr, mb.layer_ws, mb.layer_ws_bytes,
+                           l == 0 ? (kGnSkipGlobalUpdate | shared0) : mid, &pend.n_partials, stream));
     cur_g = mb.skip_g[l + 1];
     {  // graph_pooling_2x2 (hybrid_gnn.py:427, :401): node features and the four edge-feature sets
       const float* src[5] = {mb.tmp_x[0]};
@@ -652,9 +653,11 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
       GUNET_TRY(enter(&L.qg, &gw, 0, nullptr, 0, nullptr));
       pend = {&L.qg, &gw, 0, cur_g, g_out};
       // the last layer of the model finishes its own global
+      // the first layer of the last block reads the caller's edge features again (the skip graph)
+      const int shared = (l == 0 && j == 0) ? shared0 : 0;
       GUNET_TRY(gn_layer_run(&L.qg, &gw, batch, cur_x, j == 0 ? mb.skip_x[l] : nullptr, c_skip, e_in, cur_g, activation,
                              mb.tmp_x[side], e_out, last ? g_out : nullptr, mb.layer_ws, mb.layer_ws_bytes,
-                             last ? kGnSkipPrologue : mid, &pend.n_partials, stream));
+                             (last ? kGnSkipPrologue : mid) | shared, &pend.n_partials, stream));
       cur_x = mb.tmp_x[side];
       e_in = e_out == last_e ? nullptr : mb.tmp_e[side].q;
       cur_g = g_out;

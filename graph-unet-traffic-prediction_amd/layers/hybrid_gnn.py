@@ -10,7 +10,8 @@ graph dict (models/base_model.py:302-312 in the reference):
     'node_loc':   int64 [N, 2] (row, col)
     'global':     float32 [1, G]
 Batched extension (several samples on one graph): x [B, N, C], edges [B, E_q, F_e],
-global [B, G]; 2-D x is the reference's single-sample form.
+global [B, G]; 2-D x is the reference's single-sample form.  With a batched x, 2-D edge tensors
+[E_q, F_e] are taken as shared by all samples (the street-map features depend on the city only).
 """
 import ctypes as C
 import math
@@ -259,12 +260,13 @@ class GeoQuadrantGCN:
         qg = _plan.get_quadgraph(edge_index, n)
         feats = []
         f_e = None
+        shared = all(e.dim() == 2 for e in edges) and batch > 1
         for q in range(4):
             e = _as_f32(edges[q], f"graph['edges'][{q}]")
             eb = e.unsqueeze(0) if e.dim() == 2 else e
-            if eb.shape[0] != batch or eb.shape[1] != qg.n_edges[q]:
+            if eb.shape[0] != (1 if shared else batch) or eb.shape[1] != qg.n_edges[q]:
                 raise ValueError(f"graph['edges'][{q}] has shape {tuple(e.shape)}, expected "
-                                 f'[{batch}, {qg.n_edges[q]}, F]')
+                                 f'[{batch}, {qg.n_edges[q]}, F] (or [{qg.n_edges[q]}, F] shared by the batch)')
             f_e = eb.shape[2] if f_e is None else f_e
             if eb.shape[2] != f_e:
                 raise ValueError('all four edge-feature tensors must have the same width')
@@ -280,7 +282,7 @@ class GeoQuadrantGCN:
         in_ptrs = ptr4(feats)
         out_ptrs = ptr4(edges_out)
         call('gunet_gn_layer_forward_f32', C.byref(qg.struct), C.byref(ws), batch, ptr(xb), ptr(x_skip),
-             c_skip, C.byref(in_ptrs), ptr(glob), self._act, ptr(x_out), C.byref(out_ptrs),
+             c_skip, C.byref(in_ptrs), 1 if shared else 0, ptr(glob), self._act, ptr(x_out), C.byref(out_ptrs),
              ptr(global_out), ptr(scratch), scratch.numel(), current_stream(dev))
         if single:
             x_out = x_out[0]

@@ -81,19 +81,18 @@ class GraphBaseModel:
         metrics['rel_score'] = seed_metrics['mse_scaled'] * n_nodes / (n_nodes + n_zeros) / metrics['score']
         return metrics
 
-    def _city_features(self, x, batch):
+    def _city_features(self, x):
         g = x['graph']
         tk = _plan._tensor_key
         key = (tk(x['image']['street_map']), tk(g['node_loc']), tuple(tk(e) for e in g['edge_index']),
-               tk(self.cnn1_kernel), tk(self.cnn2_kernel), batch)
+               tk(self.cnn1_kernel), tk(self.cnn2_kernel))
         hit = self._city.get(key)
         if hit is not None:
             self._city.move_to_end(key)
         else:
             enc = self.forward_street_encoding(x)
-            edges = [self.compute_edge_features(enc, e) for e in g['edge_index']]      # :294-298
-            if batch is not None:
-                edges = [e.unsqueeze(0).expand(batch, -1, -1).contiguous() for e in edges]
+            # :294-298; [E_q, 16] each, shared by every sample of the city (never expanded per sample)
+            edges = [self.compute_edge_features(enc, e) for e in g['edge_index']]
             # keep the keyed tensors alive so their addresses cannot be reused by another city
             hit = (enc, edges, (x['image']['street_map'], g['node_loc'], list(g['edge_index'])))
             self._city[key] = hit
@@ -112,7 +111,7 @@ class GraphBaseModel:
         single = seeds.dim() == 2
         sb = (seeds.unsqueeze(0) if single else seeds).contiguous()
         batch, n, s_width = sb.shape
-        enc, edges = self._city_features(x, None if single else batch)
+        enc, edges = self._city_features(x)
         dev = sb.device
         t_enc = x['time_enc'][:, -1].to(torch.float32).contiguous()                       # :309
         weekday = torch.as_tensor(x['weekday']).reshape(-1).to(device=dev, dtype=torch.int32).contiguous()

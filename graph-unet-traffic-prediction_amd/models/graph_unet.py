@@ -187,12 +187,14 @@ class GraphUNet(GraphBaseModel):
         if up.n_nodes[0] != n:
             raise ValueError(f"x has {n} rows but graph['node_loc'] has {up.n_nodes[0]}")
         feats = []
+        shared = all(e.dim() == 2 for e in edges) and batch > 1      # one [E_q, F] tensor for the whole batch
         for q in range(4):
             e = _as_f32(edges[q], f"graph['edges'][{q}]")
             eb = e.unsqueeze(0) if e.dim() == 2 else e
-            if eb.shape[0] != batch or eb.shape[1] != up.n_edges[0][q] or eb.shape[2] != edges[0].shape[-1]:
+            if (eb.shape[0] != (1 if shared else batch) or eb.shape[1] != up.n_edges[0][q]
+                    or eb.shape[2] != edges[0].shape[-1]):
                 raise ValueError(f"graph['edges'][{q}] has shape {tuple(e.shape)}, expected "
-                                 f'[{batch}, {up.n_edges[0][q]}, {edges[0].shape[-1]}]')
+                                 f'[{batch}, {up.n_edges[0][q]}, {edges[0].shape[-1]}] (or 2-D, shared by the batch)')
             feats.append(eb)
         ws = self._native_weights(c_in, feats[0].shape[2], glob.shape[1], dev)
         u_last, g_last = self._native_widths
@@ -213,12 +215,13 @@ class GraphUNet(GraphBaseModel):
         with torch.cuda.device(dev):     # kernels go to the current device; the plan checks that it is its own
             if self.static_scratch:
                 call('gunet_unet_forward_static_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs),
-                     ptr(glob), _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs),
+                     1 if shared else 0, ptr(glob), _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs),
                      ptr(global_out), current_stream(dev))
             else:
                 scratch = _plan.model_workspace(nbytes, dev)
                 base = (scratch.data_ptr() + 255) // 256 * 256
-                call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
+                call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs),
+                     1 if shared else 0, ptr(glob),
                      _activation_code(self.activation), out_activation, ptr(out), C.byref(out_ptrs), ptr(global_out),
                      C.c_void_p(base), scratch.numel() - (base - scratch.data_ptr()), current_stream(dev))
         if single:

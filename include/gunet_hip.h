@@ -202,7 +202,9 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
  *   x          [B, N, c_in - c_skip]
  *   x_skip     [B, N, c_skip] or NULL (c_skip = 0): the trailing input columns, so that the caller of
  *              the up path (hybrid_gnn.py:235, x = concat(x, x_skip)) need not materialise the concat
- *   edges[q]   [B, E_q, f_e], or NULL meaning all-zero edge features
+ *   edges[q]   [B, E_q, f_e], or NULL meaning all-zero edge features; with edges_shared != 0 one
+ *              [E_q, f_e] tensor serves every sample (the street-map features of
+ *              models/base_model.py:294-298 depend on the city only)
  *   global_in  [B, g]
  *   x_out      [B, N, units]
  *   edges_out[q] [B, E_q, u]          (graph['edges'] after the call)
@@ -210,7 +212,7 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
  * units = 128 and 256 are implemented. */
 int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* weights,
                                int32_t batch, const float* x, const float* x_skip, int32_t c_skip,
-                               const float* const edges[4], const float* global_in,
+                               const float* const edges[4], int32_t edges_shared, const float* global_in,
                                int32_t activation, float* x_out, float* const edges_out[4],
                                float* global_out, void* workspace, size_t workspace_bytes,
                                gunet_stream_t stream);
@@ -293,7 +295,8 @@ typedef struct gunet_unet_weights {
 
 /* models/graph_unet.py:61-84 GraphUNet.call (diffuse_graph=False, residual=False, method 'graph',
  * use_global=True: the configuration the reference trains), for `batch` samples on the plan's graph:
- *   x [B, N, c_in], edges[q] [B, E_q, down[0].f_e], global_in [B, down[0].g]
+ *   x [B, N, c_in], edges[q] [B, E_q, down[0].f_e] (or, with edges_shared != 0, one [E_q, f_e]
+ *   tensor for all samples), global_in [B, down[0].g]
  *   out [B, N, out_units] = out_activation(out_model(...)); GUNET_ACT_RELU fuses the max(pred, 0)
  *   of models/base_model.py:325
  *   edges_out (may be NULL, as may its entries): graph['edges'] after the call, [B, E_q, u];
@@ -305,7 +308,7 @@ typedef struct gunet_unet_weights {
 size_t gunet_unet_workspace_bytes(const gunet_plan* plan, const gunet_unet_weights* weights,
                                   int32_t batch);
 int gunet_unet_forward_f32(const gunet_plan* plan, const gunet_unet_weights* weights, int32_t batch,
-                           const float* x, const float* const edges[4], const float* global_in,
+                           const float* x, const float* const edges[4], int32_t edges_shared, const float* global_in,
                            int32_t activation, int32_t out_activation, float* out,
                            float* const edges_out[4], float* global_out, void* workspace,
                            size_t workspace_bytes, gunet_stream_t stream);
@@ -322,8 +325,8 @@ int gunet_unet_forward_f32(const gunet_plan* plan, const gunet_unet_weights* wei
  * streams, two host threads) race; calls on one stream, or ordered by events, are safe. */
 #define GUNET_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
 int gunet_unet_forward_static_f32(const gunet_plan* plan, const gunet_unet_weights* weights, int32_t batch,
-                                  const float* x, const float* const edges[4], const float* global_in,
-                                  int32_t activation, int32_t out_activation, float* out,
+                                  const float* x, const float* const edges[4], int32_t edges_shared,
+                                  const float* global_in, int32_t activation, int32_t out_activation, float* out,
                                   float* const edges_out[4], float* global_out, gunet_stream_t stream);
 
 /* ------------------------------------------------------------------------

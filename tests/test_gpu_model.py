@@ -241,7 +241,7 @@ def test_unet_forward_errors(amd, oracle):
     buf = torch.empty(need + 512, dtype=torch.uint8, device='cuda')
     base = (buf.data_ptr() + 255) // 256 * 256
     feats = _lib.ptr4([e.unsqueeze(0) for e in g['edges']])
-    args = lambda nbytes: (up.handle, C.byref(ws), 1, _lib.ptr(xd), C.byref(feats), _lib.ptr(g['global']), 1, 0,
+    args = lambda nbytes: (up.handle, C.byref(ws), 1, _lib.ptr(xd), C.byref(feats), 0, _lib.ptr(g['global']), 1, 0,
                            _lib.ptr(out), None, None, C.c_void_p(base), nbytes, None)
     assert _lib.lib.gunet_unet_forward_f32(*args(need)) == 0
     torch.cuda.synchronize()
@@ -260,3 +260,67 @@ def test_unet_forward_errors(amd, oracle):
         ws.down[1].c_in = saved
     with pytest.raises(ValueError):
         model(xd[:-1], dict(g))
+
+
+def test_shared_edge_features_equal_expanded(amd, oracle):
+    """Input edge features given once for the whole batch ([E_q, F], edges_shared in the C ABI) give
+    the same bits as B per-sample copies, in the one-call forward, the layer-by-layer path and a
+    single layer; so does the 256-wide generic-free path's neighbour, the wide generic edge GEMM."""
+    x, graph, _ = make_case(oracle, 33, 29, 0.55)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    B = 3
+    rng = np.random.default_rng(5)
+    xb = to_dev(np.stack([x * rng.random(x.shape, dtype=np.float32) for _ in range(B)]))
+    results = []
+    for native in (True, False):
+        model.native_forward = native
+        for shared in (True, False):
+            g = graph_to_dev(graph)
+            g['global'] = g['global'].repeat(B, 1) * torch.arange(1, B + 1, device='cuda').reshape(B, 1)
+            if not shared:
+                g['edges'] = [e.unsqueeze(0).repeat(B, 1, 1).contiguous() for e in g['edges']]
+            y, go = model(xb, g)
+            results.append((y, go['global'], go['edges']))
+    for y, gl, ed in results[1:]:
+        assert torch.equal(y, results[0][0]) and torch.equal(gl, results[0][1])
+        assert all(torch.equal(a, b) for a, b in zip(ed, results[0][2]))
+    # a wide layer (generic edge GEMM): shared vs expanded
+    from gunet_amd.layers.hybrid_gnn import GeoQuadrantGCN
+    n = x.shape[0]
+    Wl = oracle.make_weights(oracle.gn_layer_shapes('L', 128, 16, 113, 512), 2)
+    layer = GeoQuadrantGCN(512, activation='relu', use_bias=True, use_global=True)
+    layer.load_weights(Wl, 'L', 'cuda')
+    xw = torch.rand((B, n, 128), device='cuda')
+    outs = []
+    for shared in (True, False):
+        g = graph_to_dev(graph)
+        g['global'] = g['global'].repeat(B, 1)
+        if not shared:
+            g['edges'] = [e.unsqueeze(0).repeat(B, 1, 1).contiguous() for e in g['edges']]
+        outs.append(layer(xw, g))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1]['global'], outs[1][1]['global'])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs in one process')
+def test_tensors_on_a_device_that_is_not_current(amd, oracle):
+    """Every entry point runs on the device of the stream it is given, whatever device is current:
+    model inputs, one-call forward and layer-by-layer path with all tensors on cuda:1 while cuda:0
+    is current give the bits of the same calls made with cuda:1 current."""
+    x, graph, _ = make_case(oracle, 24, 30, 0.6)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    outs = []
+    for current in (1, 0):
+        with torch.cuda.device(current):
+            model = amd.GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                                  use_bias=True, use_global=True).load_weights(W, 'cuda:1')
+            for native in (True, False):
+                model.native_forward = native
+                g = {k: ([t.to('cuda:1') for t in v] if isinstance(v, list) else v.to('cuda:1'))
+                     for k, v in graph_to_dev(graph).items()}
+                y, go = model(to_dev(x).to('cuda:1'), g)
+                torch.cuda.synchronize('cuda:1')
+                assert y.device == torch.device('cuda:1')
+                outs.append(y.cpu())
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])

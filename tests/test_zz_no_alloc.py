@@ -40,12 +40,12 @@ def _forward_pair(amd, oracle, W, size, batch, seed):
         global_out = torch.full((batch, g_last), float('nan'), dtype=torch.float32, device='cuda')
         in_ptrs, out_ptrs = ptr4(feats), ptr4(edges_out)
         if static:
-            call('gunet_unet_forward_static_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
+            call('gunet_unet_forward_static_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), 0, ptr(glob),
                  1, 1, ptr(out), C.byref(out_ptrs), ptr(global_out), current_stream(xb.device))
         else:
             scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device='cuda')
             base = (scratch.data_ptr() + 255) // 256 * 256
-            call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), ptr(glob),
+            call('gunet_unet_forward_f32', up.handle, C.byref(ws), batch, ptr(xb), C.byref(in_ptrs), 0, ptr(glob),
                  1, 1, ptr(out), C.byref(out_ptrs), ptr(global_out), C.c_void_p(base), nbytes,
                  current_stream(xb.device))
         torch.cuda.synchronize()
