@@ -159,13 +159,21 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
 #pragma unroll
     for (int n = 0; n < NT; ++n) cs[n] = 0.0f;
     const int wrow0 = row0 + 32 * wave;
-    if (g.row_map == nullptr) {
+    {
       // 16 rows x 32 columns at a time through the wave's own LDS, picked up row-wise: a store
-      // instruction then writes eight full 128-byte lines instead of two
+      // instruction then writes eight full 128-byte lines instead of two.  With a row map the
+      // pick-up lane looks its output row up (fetched here, ahead of the stores).
       float* stage = Stage[wave];
       const int srow = lane >> 3, scol = 4 * (lane & 7);
-      float* obase = g.out ? g.out + (b * g.out_rows + wrow0 + srow) * static_cast<int64_t>(g.ldo) + col0 + scol
-                           : nullptr;
+      int64_t orow[4];   // output rows of this lane's four pick-up rows: 16h + 8i + srow
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wrow0 + 8 * j + srow;
+        orow[j] = row;
+        if (g.row_map != nullptr && row < g.n_rows)
+          orow[j] = g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub;
+      }
+      float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + col0 + scol : nullptr;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -183,23 +191,8 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
             for (int i = 0; i < 2; ++i) {
               const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
               if (wrow0 + 16 * h + 8 * i + srow < g.n_rows)
-                *reinterpret_cast<float4*>(obase + static_cast<int64_t>(16 * h + 8 * i) * g.ldo + 32 * n) = v;
+                *reinterpret_cast<float4*>(obase + orow[2 * h + i] * g.ldo + 32 * n) = v;
             }
-          }
-        }
-      }
-    } else {
-      float* obase = g.out ? g.out + b * g.out_rows * static_cast<int64_t>(g.ldo) + col0 + li : nullptr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < g.n_rows) {
-          const int64_t orow = g.row_map[static_cast<int64_t>(row) * g.row_map_stride] - g.row_map_sub;
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const float v = activate(acc[n][r] + bias_v[n], g.relu);
-            if (obase) obase[orow * g.ldo + 32 * n] = v;
-            cs[n] += v;
           }
         }
       }
