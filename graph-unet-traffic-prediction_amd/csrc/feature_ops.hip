@@ -498,8 +498,11 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
   constexpr int CH = Rows::CH;
   constexpr int U = 128 * UT, u = 32 * UT;
   constexpr bool PIPE = UT == 1;   // two row buffers fit the register file only at u = 32
-  // Weight image: for 8-row chunk c and column tile t one 1 KiB piece in lane order: lane (lh, li)
-  // finds rows 8c + 4lh + 0..3 of column 32t + li as one float4 (one ds_read_b128 feeds four MFMAs).
+  // Weight image at u = 32: for 8-row chunk c one 1 KiB piece in lane order -- lane (lh, li) finds
+  // rows 8c + 4lh + 0..3 of column li as one float4, so one ds_read_b128 feeds four MFMAs.  At
+  // u = 64 the plain row-major image with one ds_read_b32 per MFMA is the faster of the two
+  // (measured A/B on the dense 256-wide workload: 18.3 against 19.9 ms per step).
+  constexpr bool LANE_IMAGE = UT == 1;
   __shared__ __attribute__((aligned(16))) float Ws[CH * 8 * u];
   __shared__ double red[4 * u];
   const int tid = threadIdx.x;
@@ -523,7 +526,10 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
         v = row < a.f_e ? w[row * u + col] : 0.0f;
       else
         v = w[(a.f_e + row - 8 * FE_CHUNKS) * u + col];
-      Ws[((((row >> 3) * UT + (col >> 5)) * 64) + ((row >> 2) & 1) * 32 + (col & 31)) * 4 + (row & 3)] = v;
+      if constexpr (LANE_IMAGE)
+        Ws[((((row >> 3) * UT + (col >> 5)) * 64) + ((row >> 2) & 1) * 32 + (col & 31)) * 4 + (row & 3)] = v;
+      else
+        Ws[i] = v;
     }
     __syncthreads();
     const float4* wl = reinterpret_cast<const float4*>(Ws) + lane;
@@ -547,8 +553,19 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
       for (int t = 0; t < UT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      if constexpr (!LANE_IMAGE) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
+        for (int c = 0; c < CH; ++c) {
+          const float a4[4] = {cur.v[c].x, cur.v[c].y, cur.v[c].z, cur.v[c].w};
+#pragma unroll
+          for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], Ws[(8 * c + 4 * lh + j) * u + 32 * t + li], acc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int c = 0; LANE_IMAGE && c < CH; ++c) {
         float4 wv[UT];
 #pragma unroll
         for (int t = 0; t < UT; ++t) wv[t] = wl[(c * UT + t) * 64];

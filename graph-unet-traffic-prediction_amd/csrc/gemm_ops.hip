@@ -38,6 +38,8 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
   constexpr int BN = 32 * NT;
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BN];
   __shared__ __attribute__((aligned(16))) float Stage[4][16 * 32];   // epilogue: one per wave
+  __shared__ double Csum[4][BN];   // per wave: column sums over the workgroup's row tiles (kept out of the registers:
+                                   // three workgroups per compute unit need the kernel below 170 of them)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -59,14 +61,19 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
   };
 
   float bias_v[NT];   // loaded up front: a load inside the epilogue would drain its stores
-  double csd[NT];
+  const bool want_cs = g.colsum != nullptr;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    if (g.bias_by_tile)
-      bias_v[n] = g.bias_tile[ct + n] ? g.bias_tile[ct + n][li] : 0.0f;
-    else
-      bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * (ct + n) + li] : 0.0f;
-    csd[n] = 0.0;
+    if (want_cs && lh == 0) Csum[wave][32 * n + li] = 0.0;
+    // NT > 1 launches are never sliced (ct = 0): constant indices into the argument arrays
+    const int tile = NT == 1 ? ct : n;
+    if (g.bias_by_tile) {
+      const float* bt = NT > 1 ? g.bias_tile[n]
+                               : (tile == 0 ? g.bias_tile[0] : (tile == 1 ? g.bias_tile[1] : (tile == 2 ? g.bias_tile[2] : g.bias_tile[3])));
+      bias_v[n] = bt ? bt[li] : 0.0f;
+    } else {
+      bias_v[n] = g.bias ? g.bias[b * g.bias_stride + 32 * tile + li] : 0.0f;
+    }
   }
 
   const int row_tiles = (g.n_rows + kBM - 1) / kBM;
@@ -78,18 +85,20 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
 
     float4 b_reg[NT];
     // this lane's operand row in each segment (a gathered segment looks it up once per row tile)
-    int64_t a_row[3];
+    int a_row[3];   // within the sample
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      a_row[s] = (s < g.n_seg && g.seg[s].shared ? 0 : b * g.n_rows) + my_row;
+      a_row[s] = my_row;
       if (s < g.n_seg && g.seg[s].row_idx != nullptr)
-        a_row[s] = b * g.seg[s].a_rows + (row_ok ? g.seg[s].row_idx[static_cast<int64_t>(my_row) * g.seg[s].idx_stride] : 0);
+        a_row[s] = row_ok ? g.seg[s].row_idx[static_cast<int64_t>(my_row) * g.seg[s].idx_stride] : 0;
     }
     auto load_a = [&](int t, float4 (&a)[4]) {
       int s, k0;
       locate(t, s, k0);
       const GemmSeg& sg = g.seg[s];
-      const float* p = sg.a + (s == 0 ? a_row[0] : (s == 1 ? a_row[1] : a_row[2])) * static_cast<int64_t>(sg.lda) + k0 + 4 * lh;
+      const int64_t sample_rows = sg.shared ? 0 : (sg.row_idx != nullptr ? sg.a_rows : g.n_rows);
+      const float* p = sg.a + (b * sample_rows + (s == 0 ? a_row[0] : (s == 1 ? a_row[1] : a_row[2]))) * static_cast<int64_t>(sg.lda) +
+                       k0 + 4 * lh;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (row_ok && k0 + 8 * c + 4 * lh < sg.k)
@@ -106,8 +115,9 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
       const int k = k0 + (tid >> 3);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
+        const float* wj = NT > 1 ? sg.w[j] : (ct == 0 ? sg.w[0] : (ct == 1 ? sg.w[1] : (ct == 2 ? sg.w[2] : sg.w[3])));
         if (k < sg.k)
-          b_reg[j] = *reinterpret_cast<const float4*>(sg.w[ct + j] + static_cast<int64_t>(k) * sg.ldw + 4 * (tid & 7));
+          b_reg[j] = *reinterpret_cast<const float4*>(wj + static_cast<int64_t>(k) * sg.ldw + 4 * (tid & 7));
         else
           b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -165,7 +175,7 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
       // pick-up lane looks its output row up (fetched here, ahead of the stores).
       float* stage = Stage[wave];
       const int srow = lane >> 3, scol = 4 * (lane & 7);
-      int64_t orow[4];   // output rows of this lane's four pick-up rows: 16h + 8i + srow
+      int orow[4];   // output rows of this lane's four pick-up rows: 16h + 8i + srow
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = wrow0 + 8 * j + srow;
@@ -191,29 +201,24 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
             for (int i = 0; i < 2; ++i) {
               const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
               if (wrow0 + 16 * h + 8 * i + srow < g.n_rows)
-                *reinterpret_cast<float4*>(obase + orow[2 * h + i] * g.ldo + 32 * n) = v;
+                *reinterpret_cast<float4*>(obase + static_cast<int64_t>(orow[2 * h + i]) * g.ldo + 32 * n) = v;
             }
           }
         }
       }
     }
-    if (g.colsum != nullptr) {
+    if (want_cs) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         cs[n] += __shfl_xor(cs[n], 32);
-        csd[n] += static_cast<double>(cs[n]);
+        if (lh == 0) Csum[wave][32 * n + li] += static_cast<double>(cs[n]);   // only this lane touches the entry
       }
     }
   }
-  if (g.colsum != nullptr) {   // one partial row per workgroup: the four waves' sums added in order
-    double* red = reinterpret_cast<double*>(&Stage[0][0]);   // 4 * BN <= 512 doubles; the staging tiles are no longer in use
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-      if (lh == 0) red[wave * BN + 32 * n + li] = csd[n];
+  if (want_cs) {   // one partial row per workgroup: the four waves' sums added in order
     __syncthreads();
     if (tid < BN) {
-      const double s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      const double s = ((Csum[0][tid] + Csum[1][tid]) + Csum[2][tid]) + Csum[3][tid];
       g.colsum[(b * g.colsum_tiles + g.colsum_tile0 + wg) * g.colsum_ld + col0 + tid] = s;
     }
   }
@@ -1001,8 +1006,8 @@ int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack
 
 // Small launches of the tiled kernel are cut into 32-column slices: the matrix work of a 128-row
 // tile is then shared by four workgroups instead of sitting in one wave per 32 rows.
-inline bool tiled_slices(int64_t workgroups, int nt) {
-  return nt > 1 && workgroups < 2 * static_cast<int64_t>(device_cu_count());
+inline bool tiled_slices(int64_t row_tiles, int nt) {   // row_tiles: 128-row tiles of the whole launch, all samples
+  return nt > 1 && row_tiles < 2 * static_cast<int64_t>(device_cu_count());
 }
 
 int launch_tiled(int nt, bool group, dim3 grid, hipStream_t stream, const GemmArgs* g, int tpw, const GemmGroup* gg) {
@@ -1107,7 +1112,7 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
   if (resident) return launch_gemm_resident(g, nt, batch, stream);
   const int tpw = tiled_tiles_per_wg(g, batch, g.colsum != nullptr);
   grid.x = static_cast<unsigned>(ceil_div(ceil_div(g.n_rows, kBM), tpw));
-  if (tiled_slices(static_cast<int64_t>(grid.x) * batch, nt)) {
+  if (tiled_slices(ceil_div(g.n_rows, kBM) * batch, nt)) {
     grid.z = static_cast<unsigned>(nt);
     nt = 1;
   }
@@ -1129,6 +1134,7 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
   }
   GemmGroup gg = {};
   unsigned blocks = 0;
+  int64_t row_tiles = 0;
   double flops = 0.0;
   for (int i = 0; i < kGemmGroup; ++i) {
     if (i < n_live) {
@@ -1137,6 +1143,7 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
       if (g.out_rows == 0) g.out_rows = g.n_rows;
       if (g.colsum_ld == 0) g.colsum_ld = 32 * nt;
       gg.tpw[i] = tiled_tiles_per_wg(g, batch, g.colsum != nullptr);
+      row_tiles += ceil_div(g.n_rows, kBM);
       blocks += static_cast<unsigned>(ceil_div(ceil_div(g.n_rows, kBM), gg.tpw[i]));
       for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt);
     } else {
@@ -1146,7 +1153,7 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
   }
   dim3 grid(blocks, static_cast<unsigned>(batch));
   ProfScope prof(kProfGemmTiled, stream, flops);
-  if (tiled_slices(static_cast<int64_t>(blocks) * batch, nt)) {
+  if (tiled_slices(row_tiles * batch, nt)) {
     grid.z = static_cast<unsigned>(nt);
     nt = 1;
   }

@@ -1,5 +1,11 @@
-"""hbm_traffic_per_launch.json from a summarize_pmc.py table:
-    python profiles/make_traffic_table.py profiles/r01_bench_n1_hbm_traffic_v4.csv > profiles/hbm_traffic_per_launch.json
+"""Add one workload's counter table to profiles/hbm_traffic_per_launch.json:
+    python profiles/make_traffic_table.py <workload key> <hbm_traffic csv of summarize_pmc.py> [note]
+e.g. python profiles/make_traffic_table.py cfg2 profiles/r02_cfg2_hbm_traffic.csv
+
+The file holds, per benchmark workload (bench.py's workload_key: cfg1, cfg2, cfg3, cfg5), the HBM
+bytes per launch of every kernel class and `source_stamp`, the hash of the library sources the
+passes were measured on (bench.py's source_stamp()); bench.py marks a table whose stamp differs from
+the sources it runs as stale.
 
 Kernel templates are merged into the classes bench.py's roofline speaks of (launch-weighted means):
 k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED> -> 'k_gemm_resident<*, NKT>' for the float32
@@ -7,9 +13,13 @@ instantiations and 'k_gemm_resident<.., bf16>' for the bf16 ones; every other ke
 without template arguments."""
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def class_of(name):
@@ -20,10 +30,13 @@ def class_of(name):
     return name.split('<')[0]
 
 
-def main(path):
+def main(key, path, note=''):
+    import bench
     acc = defaultdict(lambda: [0, 0.0, 0.0])
     with open(path) as f:
         for row in csv.DictReader(f):
+            if not row['kernel'].replace('gunet::', '').startswith('k_'):
+                continue
             n = int(row['launches'])
             a = acc[class_of(row['kernel'])]
             a[0] += n
@@ -31,10 +44,22 @@ def main(path):
             a[2] += n * float(row['write_MB_per_launch'])
     kernels = {k: {'launches': n, 'fetch_MB_per_launch': round(fe / n, 3), 'write_MB_per_launch': round(wr / n, 3),
                    'hbm_MB_per_launch': round((fe + wr) / n, 3)} for k, (n, fe, wr) in acc.items()}
-    source = (f'{path}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --steps 3 --warmup 1`, '
-              "FETCH_SIZE doubled (gfx950), averaged over each kernel class's launches")
-    json.dump({'source': source, 'kernels': kernels}, sys.stdout, indent=1)
+    out = os.path.join(ROOT, 'profiles', 'hbm_traffic_per_launch.json')
+    table = {'workloads': {}}
+    if os.path.exists(out):
+        with open(out) as f:
+            old = json.load(f)
+        if 'workloads' in old:
+            table = old
+    table['workloads'][key] = {
+        'source': (f'{os.path.relpath(path, ROOT)}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (one counter per '
+                   f'run) of the bench.py command of this workload with --steps 3 --warmup 1, FETCH_SIZE doubled (gfx950), '
+                   f"averaged over each kernel class's launches" + (f'; {note}' if note else '')),
+        'source_stamp': bench.source_stamp(), 'kernels': kernels}
+    with open(out, 'w') as f:
+        json.dump(table, f, indent=1)
+    print(key, 'stamp', table['workloads'][key]['source_stamp'], len(kernels), 'kernel classes')
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(*sys.argv[1:4])
