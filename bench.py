@@ -814,6 +814,9 @@ def run_cities(args, ranks):
     forward_all()
     ranks.sync()
     first_pass_s = time.perf_counter() - t0
+    if world > 1 and args.gather != 'none':   # first use of every sender -> collector route, outside the timed steps
+        for dst in range(world):
+            sharding.gather_rows(flat, dst=dst, counts=counts, out=gathered[0])
     elapsed = timed_steps(step, lambda: None, args, ranks)
 
     # one untimed gather to rank 0, read back: the order in which the samples arrive

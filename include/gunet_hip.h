@@ -110,7 +110,8 @@ int gunet_get_sender_receiver_f32(const float* x, int64_t n_nodes, int32_t width
 /* tf.math.unsorted_segment_max / _sum over rows (layers/hybrid_gnn.py:401,427,
  * 110).  src [B, n_src, width]; out [B, n_segments, width]; segments given as
  * CSR (rowptr, perm) from gunet_csr_from_keys.  Empty segment: -FLT_MAX (max)
- * or 0 (sum).  The sum adds rows front to back and multiplies by `scale`. */
+ * or 0 (sum).  The sum adds rows front to back and multiplies by `scale`.  The maximum is fmaxf's:
+ * a NaN among the members is dropped unless all are NaN (TensorFlow propagates it). */
 int gunet_segment_max_f32(const float* src, int64_t n_src, int32_t width, const int32_t* rowptr,
                           const int32_t* perm, int64_t n_segments, int32_t batch, float* out,
                           gunet_stream_t stream);
