@@ -324,3 +324,48 @@ def test_tensors_on_a_device_that_is_not_current(amd, oracle):
                 outs.append(y.cpu())
     for y in outs[1:]:
         assert torch.equal(y, outs[0])
+
+
+def test_plan_pool_features_and_predict_out(amd, oracle):
+    """gunet_plan_pool_features_f32 on a small graph against the oracle's graph_pooling_2x2 (bit-exact,
+    either half alone too, argument errors), and predict(out=...) writing into a caller's slice."""
+    from gunet_amd import _lib, plan
+    x, graph, _ = make_case(oracle, 31, 27, 0.6)
+    g = graph_to_dev(graph)
+    up = plan.UNetPlan(g['node_loc'], g['edge_index'], 2)
+    rng = np.random.default_rng(3)
+    B, U, u = 2, 24, 8
+    xs = rng.standard_normal((B, up.n_nodes[0], U)).astype(np.float32)
+    es = [rng.standard_normal((B, up.n_edges[0][q], u)).astype(np.float32) for q in range(4)]
+    xd, ed = to_dev(xs), [to_dev(e) for e in es]
+    xo = torch.full((B, up.n_nodes[1], U), float('nan'), device='cuda')
+    eo = [torch.full((B, up.n_edges[1][q], u), float('nan'), device='cuda') for q in range(4)]
+    src, dst = _lib.ptr4(ed), _lib.ptr4(eo)
+    stream = _lib.current_stream(xd.device)
+    _lib.call('gunet_plan_pool_features_f32', up.handle, 0, B, _lib.ptr(xd), U, C.byref(src), u, _lib.ptr(xo), C.byref(dst), stream)
+    for b in range(B):
+        gq = {'edge_index': list(graph['edge_index']), 'edges': [e[b] for e in es], 'node_loc': graph['node_loc'], 'global': None}
+        want_x, want_g = oracle.graph_pooling_2x2(xs[b], gq)
+        assert np.array_equal(xo[b].cpu().numpy(), want_x)
+        for q in range(4):
+            assert np.array_equal(eo[q][b].cpu().numpy(), want_g['edges'][q])
+    xo2 = torch.empty_like(xo)
+    _lib.call('gunet_plan_pool_features_f32', up.handle, 0, B, _lib.ptr(xd), U, None, 0, _lib.ptr(xo2), None, stream)
+    assert torch.equal(xo2, xo)
+    assert _lib.lib.gunet_plan_pool_features_f32(up.handle, 2, B, _lib.ptr(xd), U, None, 0, _lib.ptr(xo2), None, None) == -1
+    assert 'level' in _lib.last_error()
+    assert _lib.lib.gunet_plan_pool_features_f32(up.handle, 0, B, _lib.ptr(xd), U, None, 0, None, None, None) == -1
+    # predict(out=): the result lands in the caller's buffer, bit-identical to the allocating call
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    xb = to_dev(np.stack([x, x * 0.5]))
+    def batch_graph():
+        gg = graph_to_dev(graph)
+        gg['global'] = gg['global'].repeat(2, 1)
+        return gg
+    want = model.predict(xb, batch_graph())
+    buf = torch.zeros((5, x.shape[0], 96), device='cuda')
+    got = model.predict(xb, batch_graph(), out=buf[2:4])
+    assert got.data_ptr() == buf[2:4].data_ptr() and torch.equal(buf[2:4], want) and not buf[:2].any() and not buf[4:].any()
+    with pytest.raises(ValueError):
+        model.predict(xb, batch_graph(), out=buf[:3])
