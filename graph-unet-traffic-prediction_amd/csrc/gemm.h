@@ -59,6 +59,7 @@ struct GemmArgs {
   const float* gather_src[4];
   int gather_rows[4];
   float gather_scale;
+  int gather_fold;            // set by the launcher: gather_scale is a power of two and goes into the weight image
 };
 
 constexpr int kBM = 128;

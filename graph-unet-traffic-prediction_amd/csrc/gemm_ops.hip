@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <cmath>
 #include <type_traits>
 
 #include "gemm.h"
@@ -19,7 +20,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
 
+// Buffer addressing: the base address lives in scalar registers (a 4-dword resource), a lane adds a
+// 32-bit byte offset, the instruction a scalar offset and an immediate -- no 64-bit address
+// arithmetic in vector registers.  Accesses at or past `bytes` read as zero and are not written.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t BufferRsrc;
+__device__ __forceinline__ BufferRsrc buffer_of(const void* p, uint32_t bytes = 0xFFFFFFFFu) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, static_cast<int>(bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 buffer_load_f4(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, uniform_off, 0));
+}
+__device__ __forceinline__ void buffer_store_f4(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, uniform_off, 0);
+}
+
 __device__ inline float activate(float v, int relu) { return relu ? fmaxf(v, 0.0f) : v; }
+// The activation of the GEMM epilogues as one instruction: the maximum with 0 (ReLU) or with
+// -infinity (identity for every number; a NaN comes out as -infinity).  fmaxf() would first
+// canonicalise the accumulator with a second instruction.
+__device__ __forceinline__ float max_bare(float v, float floor) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(floor));
+  return r;
+}
 
 // The A operand goes straight from global memory into MFMA registers: lane (li, lh) of wave w
 // owns row 32w+li of the tile and reads floats 8c+4lh..8c+4lh+3 of every 8-float K chunk of that
@@ -268,9 +292,17 @@ constexpr size_t kResMaxLds = 160 * 1024;   // most LDS a workgroup may ask for 
 // RAGGED = true (one operand segment, float32): k is not a whole number of K tiles; the weight rows
 // past k are zero in the LDS image and the last tile's loads past k are redirected to the row's
 // first piece of that tile and zeroed.
+// Where each K tile read from the operand segments starts (sample 0, row 0) and its row stride.
+constexpr int kResMaxTiles = 12;
+struct ResidentTiles {
+  const float* a[kResMaxTiles];
+  int lda[kResMaxTiles];
+  uint32_t gather_bytes[4];   // size of each gathered source tensor (all samples)
+};
+
 template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
 __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(
-    GemmArgs g, int groups_per_sample, int bps, int gpw) {
+    GemmArgs g, ResidentTiles tl, int groups_per_sample, int bps, int gpw) {
   static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
   static_assert(!RAGGED || (!GATHER && !BF16), "the ragged form is float32 without gathering");
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
@@ -281,9 +313,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // lane (lh, li) finds rows 32kt + 8c + 4lh + 0..3 of column 32n + li as one float4.
   float* Ws = res_smem;   // [NKT][4][NT][64][4]
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // the wave number as a scalar: everything derived from it (the run of groups, the loop around
+  // them, base addresses) then stays in scalar registers
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int t0 = g.seg[0].k / kBK, t1 = g.n_seg > 1 ? g.seg[1].k / kBK : 0;   // K tiles of segments 0, 1
 
   // Paired launch: blocks i and i + 8 -- same XCD under the round-robin dispatch -- take the two
   // 32*NT-column halves of the same rows (when the pair count is no multiple of 8, the halves are
@@ -305,6 +338,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     int kbase = 0;
     for (int s = 0; s < g.n_seg; ++s) {
       const GemmSeg& sg = g.seg[s];
+      const float wscale = (GATHER && g.gather_fold && s == g.n_seg - 1) ? g.gather_scale : 1.0f;   // exact: a power of two
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float* w = (NT == 2 && half) ? sg.w[2 + t] : sg.w[t];
@@ -315,7 +349,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
             const int kg = i >> 5, col = i & 31;
             bf16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = static_cast<__bf16>(w[static_cast<int64_t>(8 * kg + j) * sg.ldw + col]);
+            for (int j = 0; j < 8; ++j) v[j] = static_cast<__bf16>(wscale * w[static_cast<int64_t>(8 * kg + j) * sg.ldw + col]);
             const int k0 = kbase + 8 * kg;   // = 16 * kstep + 8 * half
             img[((k0 >> 4) * NT + t) * 64 + ((k0 >> 3) & 1) * 32 + col] = __builtin_bit_cast(uint4, v);
           }
@@ -328,10 +362,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
               v = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(i >> 3) * sg.ldw + 4 * c4);
             // row = 8 * chunk + 4 * half + j
             float* dst = Ws + (((row >> 3) * NT + t) * 64 + ((row >> 2) & 1) * 32 + 4 * c4) * 4 + (row & 3);
-            dst[0] = v.x;
-            dst[4] = v.y;
-            dst[8] = v.z;
-            dst[12] = v.w;
+            dst[0] = wscale * v.x;
+            dst[4] = wscale * v.y;
+            dst[8] = wscale * v.z;
+            dst[12] = wscale * v.w;
           }
         }
       }
@@ -356,28 +390,26 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // for the float32 MFMA, floats 16s + 8lh + 4i + 0..3 (s, i = 0, 1) for the bf16 one.
   constexpr uint32_t kLaneFloats = BF16 ? 8u : 4u;
   auto chunk_bytes = [](int c) -> uint32_t { return BF16 ? 64u * (c >> 1) + 16u * (c & 1) : 32u * c; };
-  // uniform base pointer + 32-bit per-lane byte offset (the host checks that every operand
-  // segment and the output are smaller than 4 GiB)
+  // uniform base + 32-bit per-lane byte offset (the host checks that every operand segment and the
+  // output are smaller than 4 GiB)
   auto load_tile = [&](uint32_t arow, int kt, float4 (&a)[4]) {
-    const int s = RAGGED ? 0 : (kt < t0 ? 0 : (kt < t0 + t1 ? 1 : 2));
-    const int k0 = kBK * (kt - (s == 0 ? 0 : (s == 1 ? t0 : t0 + t1)));
-    const float* base = s == 0 ? g.seg[0].a : (s == 1 ? g.seg[1].a : g.seg[2].a);
-    const uint32_t lda = static_cast<uint32_t>(s == 0 ? g.seg[0].lda : (s == 1 ? g.seg[1].lda : g.seg[2].lda));
-    const char* sb = reinterpret_cast<const char*>(base + k0);
-    const uint32_t voff = (arow * lda + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
+    // kt is a constant after unrolling: the tile's operand address and row stride are plain fields
+    // of the argument block
+    const BufferRsrc rs = buffer_of(tl.a[kt]);
+    const uint32_t voff = (arow * static_cast<uint32_t>(tl.lda[kt]) + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
     if (RAGGED && kt == NKT - 1) {
       const int left = g.seg[0].k - kBK * (NKT - 1) - 4 * lh;   // floats of this lane's k phase left in the tile
-      const uint32_t first = static_cast<uint32_t>(arow * lda) * 4u;
+      const uint32_t first = arow * static_cast<uint32_t>(tl.lda[kt]) * 4u;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const bool ok = 8 * c < left;
-        const float4 v = *reinterpret_cast<const float4*>(sb + (ok ? voff + chunk_bytes(c) : first));
+        const float4 v = buffer_load_f4(rs, ok ? voff + chunk_bytes(c) : first, 0u);
         a[c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
       }
       return;
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const float4*>(sb + voff + chunk_bytes(c));
+    for (int c = 0; c < 4; ++c) a[c] = buffer_load_f4(rs, voff + chunk_bytes(c), 0u);
   };
 
   f32x16 acc[NT];
@@ -423,8 +455,13 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // up row-wise, so a store instruction writes eight full 128-byte lines (four floats per lane).
   const bool has_out = g.out != nullptr;
   const uint32_t ldo = static_cast<uint32_t>(g.ldo);
+  const BufferRsrc out_rs = buffer_of(g.out);
   float* stage = res_smem + (BF16 ? 16 : 32) * NKT * BN + wave * (16 * 32);
   const int srow = lane >> 3, scol = 4 * (lane & 7);
+  // this lane's pick-up position in the sample's first group, as a byte offset into the output
+  const uint32_t out_lane_off =
+      ((static_cast<uint32_t>(b) * static_cast<uint32_t>(g.out_rows) + static_cast<uint32_t>(srow)) * ldo +
+       static_cast<uint32_t>(g.out_col0 + col_shift + scol)) * 4u;
   // Column sums: the float32 sum of each group's 32 rows (16 rows per lane in a fixed order, then
   // the two half-waves), added over the wave's run of groups in float64.
   float bias_v[NT];
@@ -437,13 +474,16 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
       bias_v[n] = g.bias ? g.bias[static_cast<int64_t>(b) * g.bias_stride + col_shift + 32 * n + li] : 0.0f;
     cs[n] = 0.0;
   }
+  const float bias_one = lh == 0 ? 1.0f : 0.0f;
+  float bias_row[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bias_row[n] = lh == 0 ? bias_v[n] : 0.0f;
   const bool want_cs = g.colsum != nullptr;
+  // activation as one maximum: against 0 (ReLU) or against -infinity (identity for every number)
+  const float act_floor = g.relu ? 0.0f : -INFINITY;
   auto epilogue = [&](auto full_tag, int row0) {
     constexpr bool FULL = decltype(full_tag)::value;
-    // this lane's first pick-up row as a 32-bit byte offset; the steps between rows are uniform
-    const uint32_t voff =
-        ((static_cast<uint32_t>(b) * static_cast<uint32_t>(g.out_rows) + static_cast<uint32_t>(row0 + srow)) * ldo +
-         static_cast<uint32_t>(g.out_col0 + col_shift + scol)) * 4u;
+    const uint32_t group_off = static_cast<uint32_t>(row0) * ldo * 4u;   // uniform
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       float gs = 0.0f;   // this lane's 16 rows of column 32n + li
@@ -453,7 +493,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
         for (int r8 = 0; r8 < 8; ++r8) {
           const int r = 8 * h + r8;
           const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;   // row within this half of the tile
-          const float v = activate(acc[n][r] + bias_v[n], g.relu);
+          const float v = max_bare(acc[n][r], act_floor);
           stage[rl * 32 + li] = v;
           if (FULL || row0 + 16 * h + rl < g.n_rows) gs += v;
         }
@@ -461,9 +501,8 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
-            char* orow = reinterpret_cast<char*>(g.out + static_cast<uint32_t>(16 * h + 8 * i) * ldo);
             if (FULL || row0 + 16 * h + 8 * i + srow < g.n_rows)
-              *reinterpret_cast<float4*>(orow + voff + 128u * n) = v;
+              buffer_store_f4(out_rs, out_lane_off, group_off + static_cast<uint32_t>(16 * h + 8 * i) * ldo * 4u + 128u * n, v);
           }
         }
       }
@@ -480,27 +519,31 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // into a1 right before the MFMAs of that tile.
   int4 tab[3];
   float4 gbuf[2][4];
+  const BufferRsrc tab_rs = buffer_of(g.gather_table);
   auto load_table = [&](int grp_) {
     int row = grp_ * kRowGroup + li;
     row = row < g.n_rows ? row : g.n_rows - 1;
-    const int4* tp = reinterpret_cast<const int4*>(g.gather_table) + static_cast<int64_t>(row) * 3;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) tab[i] = tp[i];
+    for (int i = 0; i < 3; ++i)
+      tab[i] = __builtin_bit_cast(int4, buffer_load_f4(tab_rs, static_cast<uint32_t>(row) * 48u + 16u * i, 0u));
   };
   auto tab_at = [&](int i) {   // i = 3 * q + j, compile-time after unrolling
     const int4 t = tab[i >> 2];
     return (i & 3) == 0 ? t.x : ((i & 3) == 1 ? t.y : ((i & 3) == 2 ? t.z : t.w));
   };
+  // A missing table entry (-1) is read at the end of the source tensor, which the buffer's range
+  // check answers with zeros: the sum below then needs no per-entry selection.
   auto gather_issue = [&](int q, float4 (&third)[4]) {
-    const char* sb = reinterpret_cast<const char*>(g.gather_src[q]);
+    const uint32_t bytes = tl.gather_bytes[q];
+    const BufferRsrc rs = buffer_of(g.gather_src[q], bytes);
     const uint32_t base = static_cast<uint32_t>(b) * static_cast<uint32_t>(g.gather_rows[q]);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int id = tab_at(3 * q + j);
-      const uint32_t voff = ((base + static_cast<uint32_t>(id > 0 ? id : 0)) * 32u + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
+      const uint32_t voff = id >= 0 ? ((base + static_cast<uint32_t>(id)) * 32u + kLaneFloats * static_cast<uint32_t>(lh)) * 4u : bytes;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(sb + voff + chunk_bytes(c));
+        const float4 v = buffer_load_f4(rs, voff + chunk_bytes(c), 0u);
         if (j < 2)
           gbuf[j][c] = v;
         else
@@ -508,15 +551,21 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
       }
     }
   };
+  // (m0 + m1) + m2 in table order; the factor gather_scale is already in the weights when it is a
+  // power of two (gather_fold: scaling by it commutes exactly with every product)
   auto gather_reduce = [&](int q, const float4 (&third)[4], float4 (&a)[4]) {
-    const bool ok0 = tab_at(3 * q) >= 0, ok1 = tab_at(3 * q + 1) >= 0, ok2 = tab_at(3 * q + 2) >= 0;
+    (void)q;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok0) s = gbuf[0][c];
-      if (ok1) { s.x += gbuf[1][c].x; s.y += gbuf[1][c].y; s.z += gbuf[1][c].z; s.w += gbuf[1][c].w; }
-      if (ok2) { s.x += third[c].x; s.y += third[c].y; s.z += third[c].z; s.w += third[c].w; }
-      a[c] = make_float4(s.x * g.gather_scale, s.y * g.gather_scale, s.z * g.gather_scale, s.w * g.gather_scale);
+      float4 s = gbuf[0][c];
+      s.x += gbuf[1][c].x; s.y += gbuf[1][c].y; s.z += gbuf[1][c].z; s.w += gbuf[1][c].w;
+      s.x += third[c].x; s.y += third[c].y; s.z += third[c].z; s.w += third[c].w;
+      a[c] = s;
+    }
+    if (!g.gather_fold) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        a[c] = make_float4(a[c].x * g.gather_scale, a[c].y * g.gather_scale, a[c].z * g.gather_scale, a[c].w * g.gather_scale);
     }
   };
 
@@ -529,7 +578,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;   // (an inline constant of the first MFMAs, no instructions)
     if constexpr (GATHER) {
       load_table(grp);
 #pragma unroll
@@ -578,6 +627,11 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     // placed after the stores below would have to cover them as well (loads and stores share one
     // counter), and the wave would sit out its own write latency at the top of every group.
     asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x), "+v"(a0[2].x), "+v"(a0[3].x));
+    // The bias, added last as in the other GEMM kernels, by the matrix cores: one more product step
+    // whose operands are a column of ones and the bias row (k = 0; zeros at k = 1), which adds
+    // 1 * bias to every row of the tile in one rounding -- 4 instructions instead of 64 additions.
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_one, bias_row[n], acc[n], 0, 0, 0);
     const int row0 = grp * kRowGroup;
     if (row0 + kRowGroup <= g.n_rows)
       epilogue(std::true_type{}, row0);
@@ -950,7 +1004,7 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   if (g.gather_table != nullptr) {   // the last segment is the gathered one; 32-bit offsets into the sources
     if (g.n_seg < 2 || g.seg[g.n_seg - 1].k != 128) return false;
     for (int q = 0; q < 4; ++q)
-      if (batch * g.gather_rows[q] * 128 >= (int64_t{1} << 32)) return false;
+      if (batch * g.gather_rows[q] * 128 >= (int64_t{1} << 32) - 256) return false;   // + the offsets inside a row
   }
   return batch * ceil_div(g.n_rows, kRowGroup) < (1 << 30);
 }
@@ -1049,7 +1103,25 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
   const int blocks = static_cast<int>(batch * sp.bps) * (g.paired ? 2 : 1);
-  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(g, sp.groups, sp.bps, sp.gpw);
+  static_assert(NKT <= kResMaxTiles, "tile table");
+  ResidentTiles tl = {};
+  {
+    int t = 0;
+    const int n_plain = g.n_seg - (GATHER ? 1 : 0);   // the gathered segment is not read through the table
+    for (int s = 0; s < n_plain; ++s)
+      for (int k0 = 0; k0 < g.seg[s].k && t < kResMaxTiles; k0 += kBK, ++t) {
+        tl.a[t] = g.seg[s].a + k0;
+        tl.lda[t] = g.seg[s].lda;
+      }
+    GUNET_REQUIRE(t == (GATHER ? NKT - 4 : NKT), "launch_gemm: %d operand K tiles for a %d-tile kernel", t, NKT);
+  }
+  GemmArgs ga = g;
+  if (GATHER) {
+    for (int q = 0; q < 4; ++q) tl.gather_bytes[q] = static_cast<uint32_t>(batch * g.gather_rows[q] * 128);
+    int exponent = 0;
+    ga.gather_fold = g.gather_scale > 0.0f && std::frexp(g.gather_scale, &exponent) == 0.5f;
+  }
+  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(ga, tl, sp.groups, sp.bps, sp.gpw);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }

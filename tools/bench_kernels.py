@@ -30,7 +30,10 @@ def gemm():
         gunet_amd.set_matmul_mode(os.environ['GUNET_MODE'])
     rows = int(os.environ.get('GUNET_ROWS', 96493 * 8))
     for k, n in [(128, 128), (256, 128), (384, 128), (104, 128), (128, 96)]:
-        x = torch.rand((rows, k), device=dev)
+        data = os.environ.get('GUNET_DATA', 'rand')
+        x = {'rand': lambda: torch.rand((rows, k), device=dev), 'zeros': lambda: torch.zeros((rows, k), device=dev),
+             'randn': lambda: torch.randn((rows, k), device=dev),
+             'relu': lambda: torch.relu(torch.randn((rows, k), device=dev))}[data]()
         w = torch.rand((k, n), device=dev) - 0.5
         b = torch.rand((n,), device=dev)
         out = torch.empty((rows, n), device=dev)
