@@ -107,6 +107,38 @@ class ProfScope {
 
 inline hipStream_t as_stream(gunet_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// Buffer addressing for the feature kernels: the base address lives in scalar registers (a 4-dword
+// resource), a lane adds a 32-bit byte offset, the instruction a scalar offset and a 12-bit
+// immediate -- no 64-bit address arithmetic in vector registers.  Accesses at or past `bytes` read
+// as zero and are not written.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t BufferRsrc;
+__device__ __forceinline__ BufferRsrc buffer_of(const void* p, uint32_t bytes = 0xFFFFFFFFu) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, static_cast<int>(bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 buffer_load_f4(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, uniform_off, 0));
+}
+__device__ __forceinline__ int2 buffer_load_i2(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off) {
+  return __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, uniform_off, 0));
+}
+__device__ __forceinline__ void buffer_store_f4(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, uniform_off, 0);
+}
+__device__ __forceinline__ void buffer_store_f1(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, lane_off, uniform_off, 0);
+}
+
+// The activation of the matrix kernels' epilogues as one instruction: the maximum with 0 (ReLU) or
+// with -infinity (identity for every number; a NaN comes out as -infinity).  fmaxf() would first
+// canonicalise the accumulator with a second instruction.
+__device__ __forceinline__ float max_bare(float v, float floor) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(floor));
+  return r;
+}
+
 // Every entry point that takes a stream runs on that stream's device: when it is not the current
 // one (one process driving several GPUs), the guard makes it current for the length of the call, so
 // launches, temporary allocations and plan ownership all land on the GPU the stream belongs to.

@@ -19,31 +19,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
+constexpr uint32_t kOutOfBuffer = 0xFFFFF000u;   // a lane offset beyond every buffer (the launcher keeps them below that)
 
-// Buffer addressing: the base address lives in scalar registers (a 4-dword resource), a lane adds a
-// 32-bit byte offset, the instruction a scalar offset and an immediate -- no 64-bit address
-// arithmetic in vector registers.  Accesses at or past `bytes` read as zero and are not written.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t BufferRsrc;
-__device__ __forceinline__ BufferRsrc buffer_of(const void* p, uint32_t bytes = 0xFFFFFFFFu) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, static_cast<int>(bytes), 0x00020000);
-}
-__device__ __forceinline__ float4 buffer_load_f4(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off) {
-  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, uniform_off, 0));
-}
-__device__ __forceinline__ void buffer_store_f4(BufferRsrc rs, uint32_t lane_off, uint32_t uniform_off, float4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, uniform_off, 0);
-}
 
 __device__ inline float activate(float v, int relu) { return relu ? fmaxf(v, 0.0f) : v; }
-// The activation of the GEMM epilogues as one instruction: the maximum with 0 (ReLU) or with
-// -infinity (identity for every number; a NaN comes out as -infinity).  fmaxf() would first
-// canonicalise the accumulator with a second instruction.
-__device__ __forceinline__ float max_bare(float v, float floor) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(floor));
-  return r;
-}
 
 // The A operand goes straight from global memory into MFMA registers: lane (li, lh) of wave w
 // owns row 32w+li of the tile and reads floats 8c+4lh..8c+4lh+3 of every 8-float K chunk of that
@@ -66,23 +45,13 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
                                    // three workgroups per compute unit need the kernel below 170 of them)
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // a scalar, like all that follows from it
   const int li = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.y;
   const int col0 = g.out_col0 + 32 * ct;
 
   int n_tiles = 0;
   for (int s = 0; s < g.n_seg; ++s) n_tiles += (g.seg[s].k + kBK - 1) / kBK;
-  auto locate = [&](int t, int& s, int& k0) {
-    s = 0;
-    while (true) {
-      const int nt = (g.seg[s].k + kBK - 1) / kBK;
-      if (t < nt) break;
-      t -= nt;
-      ++s;
-    }
-    k0 = t * kBK;
-  };
 
   float bias_v[NT];   // loaded up front: a load inside the epilogue would drain its stores
   const bool want_cs = g.colsum != nullptr;
@@ -116,35 +85,56 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
       if (s < g.n_seg && g.seg[s].row_idx != nullptr)
         a_row[s] = row_ok ? g.seg[s].row_idx[static_cast<int64_t>(my_row) * g.seg[s].idx_stride] : 0;
     }
-    auto load_a = [&](int t, float4 (&a)[4]) {
-      int s, k0;
-      locate(t, s, k0);
-      const GemmSeg& sg = g.seg[s];
-      const int64_t sample_rows = sg.shared ? 0 : (sg.row_idx != nullptr ? sg.a_rows : g.n_rows);
-      const float* p = sg.a + (b * sample_rows + (s == 0 ? a_row[0] : (s == 1 ? a_row[1] : a_row[2]))) * static_cast<int64_t>(sg.lda) +
-                       k0 + 4 * lh;
+    // Request cursor: the K tile being fetched is columns ck0 .. ck0+31 of segment cseg.  The
+    // segment's description is read from the argument block once, when the cursor enters it; from
+    // then on a tile's addresses are a scalar base, a scalar offset that advances with ck0, and one
+    // per-lane offset.  Rows past the end of the sample or of the weight matrix sit beyond the
+    // buffers' sizes and read as zeros.
+    int cseg = -1, ck0 = 0, seg_k = 0;
+    uint32_t a_lane = 0, w_lane = 0, w_step = 0;
+    const float* a_base = nullptr;   // (plain scalars; the buffer resources are formed from them at each request)
+    const float* w_base[NT];
+    uint32_t a_bytes = 0, w_bytes = 0;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (row_ok && k0 + 8 * c + 4 * lh < sg.k)
-          a[c] = *reinterpret_cast<const float4*>(p + 8 * c);
-        else
-          a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NT; ++j) w_base[j] = nullptr;
+    auto enter = [&](int sx) {
+      const GemmSeg& sg = g.seg[sx];
+      cseg = sx;
+      ck0 = 0;
+      seg_k = sg.k;
+      const int64_t sample_rows = sg.shared ? 0 : (sg.row_idx != nullptr ? sg.a_rows : g.n_rows);
+      const int64_t rows_here = sg.row_idx != nullptr ? sg.a_rows : g.n_rows;
+      a_base = sg.a + b * sample_rows * static_cast<int64_t>(sg.lda);
+      a_bytes = static_cast<uint32_t>(rows_here) * static_cast<uint32_t>(sg.lda) * 4u;
+      const int arow = sx == 0 ? a_row[0] : (sx == 1 ? a_row[1] : a_row[2]);
+      a_lane = row_ok ? (static_cast<uint32_t>(arow) * static_cast<uint32_t>(sg.lda) + 4u * lh) * 4u : kOutOfBuffer;
+      w_step = static_cast<uint32_t>(sg.ldw) * 4u;
+      w_lane = static_cast<uint32_t>(tid >> 3) * w_step + 16u * (tid & 7);
+      w_bytes = static_cast<uint32_t>(sg.k - 1) * w_step + 128u;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        w_base[j] = NT > 1 ? sg.w[j] : (ct == 0 ? sg.w[0] : (ct == 1 ? sg.w[1] : (ct == 2 ? sg.w[2] : sg.w[3])));
+    };
+    auto advance = [&]() {   // to the next tile; the caller stops after n_tiles
+      ck0 += kBK;
+      if (ck0 >= seg_k && cseg + 1 < g.n_seg) enter(cseg + 1);
+    };
+    auto load_a = [&](float4 (&a)[4]) {
+      const BufferRsrc a_rs = buffer_of(a_base, a_bytes);
+      if (ck0 + kBK <= seg_k) {   // uniform
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = buffer_load_f4(a_rs, a_lane + 32u * c, 4u * ck0);
+      } else {   // the segment ends inside this tile (k is a multiple of 4)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          a[c] = buffer_load_f4(a_rs, ck0 + 8 * c + 4 * lh < seg_k ? a_lane + 32u * c : kOutOfBuffer, 4u * ck0);
       }
     };
-    // thread (kr = tid / 8, c4 = tid % 8) stages row k0+kr, floats 4c4..4c4+3 of every column tile
-    auto load_b = [&](int t) {
-      int s, k0;
-      locate(t, s, k0);
-      const GemmSeg& sg = g.seg[s];
-      const int k = k0 + (tid >> 3);
+    // thread (kr = tid / 8, c4 = tid % 8) stages row ck0+kr, floats 4c4..4c4+3 of every column tile
+    auto load_b = [&]() {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float* wj = NT > 1 ? sg.w[j] : (ct == 0 ? sg.w[0] : (ct == 1 ? sg.w[1] : (ct == 2 ? sg.w[2] : sg.w[3])));
-        if (k < sg.k)
-          b_reg[j] = *reinterpret_cast<const float4*>(wj + static_cast<int64_t>(k) * sg.ldw + 4 * (tid & 7));
-        else
-          b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int j = 0; j < NT; ++j)
+        b_reg[j] = buffer_load_f4(buffer_of(w_base[j], w_bytes), w_lane, static_cast<uint32_t>(ck0) * w_step);
     };
     auto store_b = [&](int buf) {
 #pragma unroll
@@ -159,15 +149,17 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
     float4 a_cur[4], a_nxt[4];
-    load_a(0, a_cur);
-    load_b(0);
+    enter(0);
+    load_a(a_cur);
+    load_b();
     store_b(0);
     __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
       const bool more = t + 1 < n_tiles;
       if (more) {
-        load_b(t + 1);
-        load_a(t + 1, a_nxt);
+        advance();
+        load_b();
+        load_a(a_nxt);
       }
       const float* bs = Bs[t & 1];
 #pragma unroll
@@ -249,7 +241,7 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
 }
 
 template <int NT>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32(GemmArgs g, int tpw) {
+__global__ __launch_bounds__(kThreads, 3) void k_gemm_f32(GemmArgs g, int tpw) {
   gemm_f32_tiles<NT>(g, blockIdx.x, tpw, blockIdx.z);
 }
 
@@ -263,7 +255,7 @@ struct GemmGroup {
 };
 
 template <int NT>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_f32_group(GemmGroup gg) {
+__global__ __launch_bounds__(kThreads, 3) void k_gemm_f32_group(GemmGroup gg) {
   int i = 0;
   while (i < kGemmGroup - 1 && blockIdx.x >= gg.block_end[i]) ++i;
   gemm_f32_tiles<NT>(gg.p[i], static_cast<int>(blockIdx.x - (i > 0 ? gg.block_end[i - 1] : 0u)), gg.tpw[i], blockIdx.z);
@@ -1064,6 +1056,15 @@ inline bool tiled_slices(int64_t row_tiles, int nt) {   // row_tiles: 128-row ti
   return nt > 1 && row_tiles < 2 * static_cast<int64_t>(device_cu_count());
 }
 
+// The tiled float32 kernel addresses every sample's operand segments with 32-bit byte offsets.
+inline bool tiled_offsets_fit(const GemmArgs& g) {
+  for (int s = 0; s < g.n_seg; ++s) {
+    const int64_t rows = g.seg[s].row_idx != nullptr ? g.seg[s].a_rows : g.n_rows;
+    if (rows * g.seg[s].lda * 4 >= static_cast<int64_t>(kOutOfBuffer)) return false;
+  }
+  return true;
+}
+
 int launch_tiled(int nt, bool group, dim3 grid, hipStream_t stream, const GemmArgs* g, int tpw, const GemmGroup* gg) {
   (void)group;
   if (g != nullptr) {
@@ -1182,6 +1183,22 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
     return launch_gemm_split<1>(g, nt, grid, wp, stream);
   }
   if (resident) return launch_gemm_resident(g, nt, batch, stream);
+  if (!tiled_offsets_fit(g)) {
+    // one flat sample without row maps or column sums (the dense entry point) goes in row chunks
+    GUNET_REQUIRE(batch == 1 && g.colsum == nullptr && g.row_map == nullptr && !gathers_rows(g) && g.out_rows == g.n_rows,
+                  "launch_gemm: an operand of %d rows per sample is beyond the 4 GiB the tiled kernel addresses", g.n_rows);
+    int64_t widest = 1;
+    for (int s = 0; s < g.n_seg; ++s) widest = std::max<int64_t>(widest, g.seg[s].lda);
+    const int chunk = static_cast<int>((int64_t{1} << 31) / (widest * 4) / kBM * kBM);
+    for (int r0 = 0; r0 < g.n_rows; r0 += chunk) {
+      GemmArgs gc = g;
+      gc.n_rows = gc.out_rows = std::min(chunk, g.n_rows - r0);
+      for (int s = 0; s < g.n_seg; ++s) gc.seg[s].a = g.seg[s].a + static_cast<int64_t>(r0) * g.seg[s].lda;
+      if (g.out != nullptr) gc.out = g.out + static_cast<int64_t>(r0) * g.ldo;
+      GUNET_TRY(launch_gemm(gc, nt, batch, wpack, stream));
+    }
+    return GUNET_OK;
+  }
   const int tpw = tiled_tiles_per_wg(g, batch, g.colsum != nullptr);
   grid.x = static_cast<unsigned>(ceil_div(ceil_div(g.n_rows, kBM), tpw));
   if (tiled_slices(ceil_div(g.n_rows, kBM) * batch, nt)) {
@@ -1212,6 +1229,8 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
     if (i < n_live) {
       gg.p[i] = gs[live[i]];
       GemmArgs& g = gg.p[i];
+      GUNET_REQUIRE(tiled_offsets_fit(g), "launch_gemm_group: an operand of %d rows per sample is beyond the 4 GiB the "
+                    "tiled kernel addresses", g.n_rows);
       if (g.out_rows == 0) g.out_rows = g.n_rows;
       if (g.colsum_ld == 0) g.colsum_ld = 32 * nt;
       gg.tpw[i] = tiled_tiles_per_wg(g, batch, g.colsum != nullptr);
