@@ -1,7 +1,7 @@
 // Ceiling of v_mfma_f32_32x32x2_f32 on gfx950 as a function of operand data and of where the B
 // operand comes from.  Development tool, not part of the library.
-//   build: hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o gpurun_out/mfma_peak
-//   run:   gpurun_out/mfma_peak
+//   build: hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o tools/bin/mfma_peak   (tools/bin/ is not tracked)
+//   run:   tools/bin/mfma_peak [iterations per launch, default 400]
 // Variants:
 //   reg      A and B fragments live in registers for the whole loop (no memory at all)
 //   lds1     B fragments re-read from LDS every step (one ds_read_b128 per 4 MFMAs and column tile),
