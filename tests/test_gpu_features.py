@@ -57,6 +57,30 @@ def test_dense_forward(amd):
             assert_close(got, want, TOL, str((rows, k, n)))
 
 
+def test_dense_forward_operand_beyond_4_gib(amd):
+    """An operand larger than the 4 GiB a kernel addresses with 32-bit offsets is worked off in row
+    chunks; checked on rows on both sides of the chunk boundary and at the end (float64 products of
+    those rows as the reference)."""
+    rows, k, n = 600_000, 2048, 128   # 4.9 GB of float32 input
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.empty((rows, k), device='cuda', dtype=torch.float32)
+    for r0 in range(0, rows, 100_000):   # filled piecewise: no second 4.9 GB temporary
+        x[r0:r0 + 100_000].normal_(generator=gen)
+    w = torch.randn((k, n), device='cuda', generator=gen) * 0.05
+    b = torch.randn((n,), device='cuda', generator=gen)
+    layer = amd.hybrid_gnn.Dense(n, activation='relu', use_bias=True)
+    layer.load_weights({'d/kernel': w.cpu().numpy(), 'd/bias': b.cpu().numpy()}, 'd', 'cuda')
+    got = layer(x)
+    torch.cuda.synchronize()
+    assert got.shape == (rows, n)
+    chunk = (1 << 31) // (k * 4) // 128 * 128   # rows per chunk of the library's split
+    picks = torch.tensor(sorted({0, 1, 127, 128, chunk - 1, chunk, chunk + 1, 2 * chunk - 1, 2 * chunk, rows - 129, rows - 1}),
+                         device='cuda')
+    want = torch.relu(x[picks].double() @ w.double() + b.double()).cpu().numpy()
+    assert_close(got[picks].cpu().numpy(), want, TOL, 'rows around the chunk boundaries')
+    del x, got
+
+
 def test_get_sender_receiver(amd, oracle):
     rng = np.random.Generator(np.random.PCG64(3))
     for width in (32, 7):
