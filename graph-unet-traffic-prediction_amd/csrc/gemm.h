@@ -120,6 +120,7 @@ inline int columns_nt(const GemmArgs& g) {
 inline int columns_colsum_rows(const GemmArgs& g, int units, int64_t batch, const void* wpack) {
   GemmArgs gc = g;
   gc.ldo = units;
+  gc.paired = columns_nt(g) == 2 && units % 128 == 0;   // as launch_gemm_columns will launch it
   return gemm_colsum_rows(gc, columns_nt(g), batch, wpack);
 }
 

@@ -1012,10 +1012,11 @@ struct ResidentSplit {
   int groups, bps, gpw;
 };
 
-inline ResidentSplit resident_split(int n_rows, int64_t batch, int block_waves) {
+inline ResidentSplit resident_split(int n_rows, int64_t batch, int block_waves, bool paired) {
   ResidentSplit r;
   r.groups = static_cast<int>(ceil_div(n_rows, kRowGroup));
-  const int64_t want = std::max<int64_t>(1, device_cu_count() / batch);                 // workgroups per sample
+  // workgroups per sample (a paired launch runs two per row range: both in the same round of workgroups)
+  const int64_t want = std::max<int64_t>(1, device_cu_count() / (batch * (paired ? 2 : 1)));
   const int64_t bps = std::min<int64_t>(want, ceil_div(r.groups, block_waves));
   r.gpw = static_cast<int>(ceil_div(r.groups, bps * block_waves));
   r.bps = static_cast<int>(ceil_div(r.groups, static_cast<int64_t>(r.gpw) * block_waves));   // no empty workgroups
@@ -1044,7 +1045,7 @@ inline int tiled_tiles_per_wg(const GemmArgs& g, int64_t batch, bool with_colsum
 // Rows of column-sum partials per sample that a launch writes (from colsum_tile0 on).
 int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack) {
   if (g.n_rows == 0) return 0;
-  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, resident_block_waves(g, nt)).bps;
+  if (takes_resident(g, nt, batch, wpack)) return resident_split(g.n_rows, batch, resident_block_waves(g, nt), g.paired != 0).bps;
   const int64_t tiles = ceil_div(g.n_rows, kBM);
   if (takes_split(wpack) && !gathers_rows(g)) return static_cast<int>(tiles);
   return static_cast<int>(ceil_div(tiles, tiled_tiles_per_wg(g, batch, true)));
@@ -1102,7 +1103,7 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
     raised[dev].store(true, std::memory_order_release);
   }
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
-  const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves);
+  const ResidentSplit sp = resident_split(g.n_rows, batch, kWaves, g.paired != 0);
   const int blocks = static_cast<int>(batch * sp.bps) * (g.paired ? 2 : 1);
   static_assert(NKT <= kResMaxTiles, "tile table");
   ResidentTiles tl = {};
