@@ -964,6 +964,11 @@ inline bool gathers_rows(const GemmArgs& g) {   // operand addressing only the t
   return false;
 }
 
+// Waves per workgroup of the resident kernel a launch gets.
+inline int resident_block_waves(const GemmArgs& g, int nt) {
+  return (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves;
+}
+
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   if (g.row_map != nullptr || gathers_rows(g)) return false;
   if (mode_pieces(g_matmul_mode) > 1) return false;   // split-bf16 modes: tiled kernel only
@@ -990,7 +995,7 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   if (g_kernel_choice == GUNET_KERNELS_TILED) return false;
   if (g_kernel_choice == GUNET_KERNELS_AUTO) {
     const int64_t groups = batch * ceil_div(g.n_rows, kRowGroup);
-    const int64_t waves = static_cast<int64_t>(device_cu_count()) * kResWaves;
+    const int64_t waves = static_cast<int64_t>(device_cu_count()) * resident_block_waves(g, nt);
     if (g.gather_table == nullptr ? groups < 2 * waves : 2 * groups < waves) return false;
   }
   if (g.gather_table != nullptr) {   // the last segment is the gathered one; 32-bit offsets into the sources
@@ -999,11 +1004,6 @@ inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
       if (batch * g.gather_rows[q] * 128 >= (int64_t{1} << 32) - 256) return false;   // + the offsets inside a row
   }
   return batch * ceil_div(g.n_rows, kRowGroup) < (1 << 30);
-}
-
-// Waves per workgroup of the resident kernel a launch gets.
-inline int resident_block_waves(const GemmArgs& g, int nt) {
-  return (g.gather_table != nullptr && nt == 4) ? kResGatherWaves : kResWaves;
 }
 
 // Work split of the resident kernel: every sample's row groups in runs of gpw, one run per wave,
