@@ -130,9 +130,9 @@ __device__ __forceinline__ void buffer_store_f1(BufferRsrc rs, uint32_t lane_off
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, lane_off, uniform_off, 0);
 }
 
-// The activation of the matrix kernels' epilogues as one instruction: the maximum with 0 (ReLU) or
-// with -infinity (identity for every number; a NaN comes out as -infinity).  fmaxf() would first
-// canonicalise the accumulator with a second instruction.
+// The ReLU of the matrix kernels' epilogues as one instruction: the maximum with 0 (a NaN comes
+// out as 0, as from fmaxf; TensorFlow's ReLU hands a NaN on).  fmaxf() would first canonicalise the
+// accumulator with a second instruction.
 __device__ __forceinline__ float max_bare(float v, float floor) {
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(floor));

@@ -19,7 +19,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
-constexpr uint32_t kOutOfBuffer = 0xFFFFF000u;   // a lane offset beyond every buffer (the launcher keeps them below that)
+// A lane offset beyond every buffer: the launcher keeps operands below 2 GiB, and adding a tile's
+// chunk and K offsets (a few KiB) to it cannot wrap around to an address inside one.
+constexpr uint32_t kOutOfBuffer = 0x80000000u;
 
 
 __device__ inline float activate(float v, int relu) { return relu ? fmaxf(v, 0.0f) : v; }
@@ -134,7 +136,9 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
     auto load_b = [&]() {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        b_reg[j] = buffer_load_f4(buffer_of(w_base[j], w_bytes), w_lane, static_cast<uint32_t>(ck0) * w_step);
+        // the row offset rides in the range-checked lane offset (a scalar offset is not checked):
+        // weight rows past k read as zeros whatever lies behind them in memory
+        b_reg[j] = buffer_load_f4(buffer_of(w_base[j], w_bytes), w_lane + static_cast<uint32_t>(ck0) * w_step, 0u);
     };
     auto store_b = [&](int buf) {
 #pragma unroll
@@ -471,10 +475,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
   for (int n = 0; n < NT; ++n) bias_row[n] = lh == 0 ? bias_v[n] : 0.0f;
   const bool want_cs = g.colsum != nullptr;
-  // activation as one maximum: against 0 (ReLU) or against -infinity (identity for every number)
-  const float act_floor = g.relu ? 0.0f : -INFINITY;
-  auto epilogue = [&](auto full_tag, int row0) {
+  // activation: one bare maximum against 0 (ReLU), or nothing at all (linear: a NaN stays a NaN)
+  auto epilogue = [&](auto full_tag, auto relu_tag, int row0) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr bool RELU = decltype(relu_tag)::value;
     const uint32_t group_off = static_cast<uint32_t>(row0) * ldo * 4u;   // uniform
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -485,7 +489,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
         for (int r8 = 0; r8 < 8; ++r8) {
           const int r = 8 * h + r8;
           const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;   // row within this half of the tile
-          const float v = max_bare(acc[n][r], act_floor);
+          const float v = RELU ? max_bare(acc[n][r], 0.0f) : acc[n][r];
           stage[rl * 32 + li] = v;
           if (FULL || row0 + 16 * h + rl < g.n_rows) gs += v;
         }
@@ -625,10 +629,17 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_one, bias_row[n], acc[n], 0, 0, 0);
     const int row0 = grp * kRowGroup;
-    if (row0 + kRowGroup <= g.n_rows)
-      epilogue(std::true_type{}, row0);
-    else
-      epilogue(std::false_type{}, row0);
+    if (g.relu) {
+      if (row0 + kRowGroup <= g.n_rows)
+        epilogue(std::true_type{}, std::true_type{}, row0);
+      else
+        epilogue(std::false_type{}, std::true_type{}, row0);
+    } else {
+      if (row0 + kRowGroup <= g.n_rows)
+        epilogue(std::true_type{}, std::false_type{}, row0);
+      else
+        epilogue(std::false_type{}, std::false_type{}, row0);
+    }
     if (!has_next) break;
     ++grp;
     cur = nxt;
@@ -1187,10 +1198,10 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
   if (!tiled_offsets_fit(g)) {
     // one flat sample without row maps or column sums (the dense entry point) goes in row chunks
     GUNET_REQUIRE(batch == 1 && g.colsum == nullptr && g.row_map == nullptr && !gathers_rows(g) && g.out_rows == g.n_rows,
-                  "launch_gemm: an operand of %d rows per sample is beyond the 4 GiB the tiled kernel addresses", g.n_rows);
+                  "launch_gemm: an operand of %d rows per sample is beyond the 2 GiB the tiled kernel addresses", g.n_rows);
     int64_t widest = 1;
     for (int s = 0; s < g.n_seg; ++s) widest = std::max<int64_t>(widest, g.seg[s].lda);
-    const int chunk = static_cast<int>((int64_t{1} << 31) / (widest * 4) / kBM * kBM);
+    const int chunk = static_cast<int>((int64_t{1} << 30) / (widest * 4) / kBM * kBM);
     for (int r0 = 0; r0 < g.n_rows; r0 += chunk) {
       GemmArgs gc = g;
       gc.n_rows = gc.out_rows = std::min(chunk, g.n_rows - r0);
@@ -1230,7 +1241,7 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
     if (i < n_live) {
       gg.p[i] = gs[live[i]];
       GemmArgs& g = gg.p[i];
-      GUNET_REQUIRE(tiled_offsets_fit(g), "launch_gemm_group: an operand of %d rows per sample is beyond the 4 GiB the "
+      GUNET_REQUIRE(tiled_offsets_fit(g), "launch_gemm_group: an operand of %d rows per sample is beyond the 2 GiB the "
                     "tiled kernel addresses", g.n_rows);
       if (g.out_rows == 0) g.out_rows = g.n_rows;
       if (g.colsum_ld == 0) g.colsum_ld = 32 * nt;

@@ -373,6 +373,11 @@ int gunet_plan_create(const int64_t* node_loc, int64_t n_nodes, const int32_t* c
   P->depth = depth;
   int rc = hipGetDevice(&P->device) == hipSuccess ? GUNET_OK : GUNET_ERR_HIP;
   if (rc != GUNET_OK) set_error("plan_create: hipGetDevice failed");
+  // the address of this device's static scratch buffer is looked up here, where allocating and
+  // synchronising are allowed, so that gunet_unet_forward_static_f32 -- which needs a plan --
+  // never makes a first-time runtime query of its own (it may run under stream capture)
+  void* static_base = nullptr;
+  if (rc == GUNET_OK) rc = static_scratch_of(P->device, &static_base);
   if (rc == GUNET_OK) rc = build_plan(*P, node_loc, n_nodes, edge_index, n_edges, as_stream(stream));
   if (rc != GUNET_OK) {
     delete P;

@@ -45,8 +45,13 @@ def _lookup(cache, key):
 
 def _tensor_key(t):
     """Identity of an index tensor's contents as far as torch can tell: its storage address, row
-    count and in-place version counter (bumped by every in-place edit through torch)."""
-    return (t.data_ptr(), int(t.shape[0]), int(t._version))
+    count and in-place version counter (bumped by every in-place edit through torch).  Tensors
+    made under torch.inference_mode() keep no counter (reading it raises); they get -1."""
+    try:
+        version = int(t._version)
+    except RuntimeError:
+        version = -1
+    return (t.data_ptr(), int(t.shape[0]), version)
 
 
 def clear_caches():
@@ -341,15 +346,24 @@ class WorkspaceScope:
         return False
 
 
+_WORKSPACE_STREAMS = 4   # buffers kept per table: the streams used most recently
+
+
 def _grown(table, nbytes, device, slack):
     # one buffer per (device, stream): kernels of one stream use it in order, two streams never
-    # share one, so forwards issued on different streams of a device cannot race on scratch
+    # share one, so forwards issued on different streams of a device cannot race on scratch.
+    # Only the most recently used streams keep theirs: a server that runs forwards on many or
+    # short-lived streams would otherwise hold one whole-model buffer per stream handle ever seen.
+    # An evicted buffer goes back to torch's allocator, which hands it out again only after the
+    # work queued on its stream has finished with it.
     key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
-    buf = table.get(key)
+    buf = table.pop(key, None)
     if buf is None or buf.numel() < nbytes:
-        table[key] = None            # let go of the old buffer before asking for the new one
+        buf = None                   # let go of the old buffer before asking for the new one
         buf = torch.empty(int(nbytes * slack) + 256, dtype=torch.uint8, device=device)
-        table[key] = buf
+    table[key] = buf                 # (re-)inserted last = most recently used
+    while len(table) > _WORKSPACE_STREAMS * max(1, torch.cuda.device_count()):
+        del table[next(iter(table))]
     return buf
 
 

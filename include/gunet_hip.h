@@ -210,7 +210,10 @@ size_t gunet_gn_layer_workspace_bytes(const gunet_quadgraph* graph, int32_t batc
  *   x_out      [B, N, units]
  *   edges_out[q] [B, E_q, u]          (graph['edges'] after the call)
  *   global_out [B, units], or [B, g + units + u] when globt_w == NULL
- * units = 128 and 256 are implemented. */
+ * units = 128, 256 (tuned kernels), 512 and 1024 (generic kernels) are implemented; other widths
+ * return GUNET_ERR_UNSUPPORTED.
+ * NaN handling: a linear layer hands a NaN on; the ReLU of a NaN is 0 here (fmaxf), NaN in
+ * TensorFlow -- a diverged input shows in the linear in/out layers, not behind a ReLU. */
 int gunet_gn_layer_forward_f32(const gunet_quadgraph* graph, const gunet_gn_weights* weights,
                                int32_t batch, const float* x, const float* x_skip, int32_t c_skip,
                                const float* const edges[4], int32_t edges_shared, const float* global_in,
@@ -272,7 +275,9 @@ int gunet_plan_upsampling(const gunet_plan* plan, int32_t level, gunet_quadgraph
  * cluster) and, per quadrant, edges_out[q] [B, E_{l+1,q}, edge_width] = the maximum of
  * edges[q] [B, E_lq, edge_width] over the fine edges that map to each pooled edge (self-loops
  * dropped).  Either half may be left out (x = x_out = NULL, or edges = edges_out = NULL).
- * Asynchronous on `stream`, allocates nothing.  Maxima are exact: bit-identical to the reference. */
+ * Asynchronous on `stream`, allocates nothing.  Maxima are exact: bit-identical to the reference for
+ * inputs without NaNs (a NaN among the members is dropped unless all are NaN, see
+ * gunet_segment_max_f32; TensorFlow hands it on). */
 int gunet_plan_pool_features_f32(const gunet_plan* plan, int32_t level, int32_t batch, const float* x,
                                  int32_t width, const float* const edges[4], int32_t edge_width,
                                  float* x_out, float* const edges_out[4], gunet_stream_t stream);

@@ -60,6 +60,20 @@ def assert_close(got, want, tol=1e-5, what=''):
     return n, e
 
 
+def assert_bracketed(got, want32, exact, tol=1e-5, what=''):
+    """The parity gate that does not depend on where an absolute floor is put: `exact` is the same
+    computation in float64, `want32` the float32 oracle.  The result under test must be within `tol`
+    of the exact value normwise, and no further from it than twice the float32 oracle is -- normwise,
+    and elementwise with the floor three decades below the tensor's scale (where two float32
+    evaluations of a long dot product no longer agree to 1e-5 with each other, only with the exact
+    value to the same degree)."""
+    hip, ora = rel_err(got, exact), rel_err(want32, exact)
+    assert hip <= tol and hip <= 2 * ora + 1e-7, f'{what}: normwise {hip:.2e} (the float32 oracle: {ora:.2e})'
+    hip_e, ora_e = elementwise_err(got, exact, 1e-3), elementwise_err(want32, exact, 1e-3)
+    assert hip_e <= 2 * ora_e + 1e-6, f'{what}: elementwise {hip_e:.2e} (the float32 oracle: {ora_e:.2e})'
+    return hip, ora, hip_e, ora_e
+
+
 @pytest.fixture(scope='session')
 def oracle():
     import gunet_oracle

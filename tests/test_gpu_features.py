@@ -58,7 +58,7 @@ def test_dense_forward(amd):
 
 
 def test_dense_forward_operand_beyond_4_gib(amd):
-    """An operand larger than the 4 GiB a kernel addresses with 32-bit offsets is worked off in row
+    """An operand larger than the 2 GiB the tiled kernel addresses with 32-bit offsets is worked off in row
     chunks; checked on rows on both sides of the chunk boundary and at the end (float64 products of
     those rows as the reference)."""
     rows, k, n = 600_000, 2048, 128   # 4.9 GB of float32 input
@@ -73,7 +73,7 @@ def test_dense_forward_operand_beyond_4_gib(amd):
     got = layer(x)
     torch.cuda.synchronize()
     assert got.shape == (rows, n)
-    chunk = (1 << 31) // (k * 4) // 128 * 128   # rows per chunk of the library's split
+    chunk = (1 << 30) // (k * 4) // 128 * 128   # rows per chunk of the library's split
     picks = torch.tensor(sorted({0, 1, 127, 128, chunk - 1, chunk, chunk + 1, 2 * chunk - 1, 2 * chunk, rows - 129, rows - 1}),
                          device='cuda')
     want = torch.relu(x[picks].double() @ w.double() + b.double()).cpu().numpy()
@@ -330,6 +330,124 @@ def test_matmul_modes(amd, oracle, mode, tol):
         assert rel_err(got_y, want_y) > 1e-5           # the mode really is on
     with pytest.raises(amd.GunetError):
         amd._lib.call('gunet_set_matmul_mode', 17)
+
+
+@pytest.mark.parametrize('size', [(40, 52, 0.45), (23, 31, 0.6)])
+def test_bf16_mode_resident_kernels_against_oracle(amd, oracle, size):
+    """The bf16 mode with every GEMM forced onto the weights-resident kernels -- the ones a full-size
+    graph takes -- on small graphs, against the float32 oracle: 2e-2 normwise, the bf16 gate.  The
+    default choice would give a graph this small the tiled kernels."""
+    x, graph, _ = make_case(oracle, *size)
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    amd.set_matmul_mode('bf16')
+    amd.set_kernel_choice('resident')
+    try:
+        got_y, got_g = _unet(amd, oracle, W)(to_dev(x), graph_to_dev(graph))
+        got_y, got_glob = got_y.cpu().numpy(), got_g['global'].cpu().numpy()
+        got_e = [e.cpu().numpy() for e in got_g['edges']]
+    finally:
+        amd.set_kernel_choice('auto')
+        amd.set_matmul_mode('f32')
+    assert np.isfinite(got_y).all()
+    assert rel_err(got_y, want_y) <= 2e-2, rel_err(got_y, want_y)
+    assert rel_err(got_glob, want_g['global']) <= 2e-2
+    for q in range(4):
+        assert got_e[q].dtype == np.float32 and rel_err(got_e[q], want_g['edges'][q]) <= 2e-2
+    assert rel_err(got_y, want_y) > 1e-5               # the mode really is on
+
+
+def test_bf16_mode_single_layer_with_skip_segment(amd, oracle, resident_kernels):
+    """One GN layer in bf16 mode on the resident kernels, with a skip segment (three operand segments
+    of the node MLP) and 16 edge features: node features, messages and global against the oracle at
+    the bf16 gate."""
+    node_loc, ei, d, _ = oracle.synth_road_graph(29, 37, 0.55, 17)
+    quads = list(oracle.sample_quadrant_subgraphs(ei, d))
+    rng = np.random.Generator(np.random.PCG64(19))
+    n = node_loc.shape[0]
+    x = (rng.random((n, 256)) - 0.3).astype(np.float32)
+    graph = {'edge_index': quads, 'node_loc': node_loc,
+             'edges': [rng.random((q.shape[0], 16)).astype(np.float32) for q in quads],
+             'global': rng.random((1, 128)).astype(np.float32)}
+    W = _layer_weights(oracle, 'L', 256, 16, 128)
+    want_x, want_g = oracle.geo_quadrant_gcn(x, copy_graph(graph), W, 'L')
+    layer = amd.hybrid_gnn.GeoQuadrantGCN(128, activation='relu', use_bias=True, use_global=True)
+    layer.load_weights(W, 'L', 'cuda')
+    xt = to_dev(x)
+    amd.set_matmul_mode('bf16')
+    try:
+        got_x, got_g = layer._forward(xt[:, :128].contiguous(), graph_to_dev(graph), x_skip=xt[:, 128:].contiguous())
+        torch.cuda.synchronize()
+    finally:
+        amd.set_matmul_mode('f32')
+    assert rel_err(got_x.cpu().numpy(), want_x) <= 2e-2
+    assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= 2e-2
+    for q in range(4):
+        assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= 2e-2
+
+
+def test_tiled_gemm_k_tail_reads_zeros_not_memory(amd):
+    """A K segment that is wide (beyond 1024 columns) and no whole number of 32-wide K tiles, on the
+    tiled kernel: the columns of the last tile past k must enter as zeros whatever lies behind the
+    operand row and behind the weight matrix in memory -- here NaNs."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    rows, k, n = 777, 1044, 128
+    xbuf = torch.full((rows * k + 4096,), float('nan'), device='cuda')
+    wbuf = torch.full(((k + 64) * n,), float('nan'), device='cuda')
+    x = rng.standard_normal((rows, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    xbuf[:rows * k] = to_dev(x).reshape(-1)
+    wbuf[:k * n] = to_dev(w).reshape(-1)
+    layer = amd.hybrid_gnn.Dense(n, activation='relu', use_bias=True)
+    layer.load_weights({'d/kernel': w, 'd/bias': b}, 'd', 'cuda')
+    layer.kernel = wbuf[:k * n].view(k, n)          # the same values with NaNs right behind the last row
+    amd.set_kernel_choice('tiled')
+    try:
+        got = layer(xbuf[:rows * k].view(rows, k)).cpu().numpy()
+    finally:
+        amd.set_kernel_choice('auto')
+    want = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0)
+    assert np.isfinite(got).all()
+    assert_close(got, want, TOL)
+
+
+def test_segment_max_nan_is_dropped_unless_alone(amd):
+    """gunet_segment_max_f32 takes fmaxf's maximum: a NaN among the members of a segment is dropped,
+    a segment of NaNs only gives NaN, an empty segment -FLT_MAX (TensorFlow's unsorted_segment_max
+    would hand the NaN on; the deviation is documented in the header)."""
+    from gunet_amd import _lib, plan
+    nan = float('nan')
+    src = torch.tensor([[1.0, nan, 3.0, -2.0], [nan, nan, 0.5, -7.0], [2.0, nan, nan, nan], [5.0, 6.0, 7.0, 8.0]], device='cuda')
+    keys = torch.tensor([0, 0, 0, 2], dtype=torch.int32, device='cuda')      # segment 1 is empty
+    rowptr, perm = plan.csr_from_keys(keys, 3)
+    out = torch.empty((3, 4), device='cuda')
+    _lib.call('gunet_segment_max_f32', _lib.ptr(src), 4, 4, _lib.ptr(rowptr), _lib.ptr(perm), 3, 1, _lib.ptr(out),
+              _lib.current_stream(src.device))
+    got = out.cpu().numpy()
+    lowest = -np.finfo(np.float32).max
+    assert got[0, 0] == 2.0 and np.isnan(got[0, 1]) and got[0, 2] == 3.0 and got[0, 3] == -2.0
+    assert (got[1] == lowest).all()
+    assert np.array_equal(got[2], [5.0, 6.0, 7.0, 8.0])
+
+
+def test_dense_linear_keeps_nan(amd, resident_kernels):
+    """A linear Dense layer hands a NaN on (as TensorFlow's does) on both GEMM families; ReLU of a NaN
+    is 0 here (fmaxf), NaN in TensorFlow -- the documented deviation."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.standard_normal((500, 128)).astype(np.float32)
+    x[7, 3] = np.nan
+    w = (rng.standard_normal((128, 128)) * 0.1).astype(np.float32)
+    for choice in ('resident', 'tiled'):
+        amd.set_kernel_choice(choice)
+        lin = amd.hybrid_gnn.Dense(128, use_bias=False)
+        lin.load_weights({'d/kernel': w}, 'd', 'cuda')
+        got = lin(to_dev(x)).cpu().numpy()
+        assert np.isnan(got[7]).all() and np.isfinite(np.delete(got, 7, axis=0)).all(), choice
+        relu = amd.hybrid_gnn.Dense(128, activation='relu', use_bias=False)
+        relu.load_weights({'d/kernel': w}, 'd', 'cuda')
+        got = relu(to_dev(x)).cpu().numpy()
+        assert (got[7] == 0).all() and np.isfinite(got).all(), choice
 
 
 def test_gn_layer_arbitrary_graph(amd, oracle):

@@ -69,6 +69,58 @@ def test_static_scratch_forward_matches_workspace_forward(oracle):
     assert sizes[1] < sizes[0]
 
 
+def test_static_scratch_forward_allocates_nothing_and_runs_under_capture(oracle):
+    """Device memory in use is the same before and after a call (hipMemGetInfo through torch), and
+    the call can be recorded into a HIP graph right after its plan was made -- the plan's creation
+    has already looked up the buffer's address -- and replayed with the eager call's bits."""
+    import gunet_amd as amd
+    from gunet_amd import plan
+    from gunet_amd._lib import call, current_stream, ptr, ptr4
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    x, graph, _ = make_case(oracle, 44, 38, 0.5, graph_seed=9, sample_seed=10)
+    model = amd.GraphUNet(32, out_units=96, depth=3, activation='relu', layer_type='geo_quadrant_gcn',
+                          use_bias=True, use_global=True, output_activation=None).load_weights(W, 'cuda')
+    g = graph_to_dev(graph)
+    xb = to_dev(x[None], torch.float32)
+    feats = [e.unsqueeze(0).contiguous() for e in g['edges']]
+    glob = g['global'].contiguous()
+    up = plan.get_unet_plan(g['node_loc'], g['edge_index'], 3)
+    ws = model._native_weights(xb.shape[2], feats[0].shape[2], glob.shape[1], xb.device)
+    u_last, g_last = model._native_widths
+    n = xb.shape[1]
+
+    def buffers():
+        return (torch.full((1, n, 96), float('nan'), device='cuda'),
+                [torch.full((1, up.n_edges[0][q], u_last), float('nan'), device='cuda') for q in range(4)],
+                torch.full((1, g_last), float('nan'), device='cuda'))
+
+    def run(out, edges_out, global_out, stream):
+        in_ptrs, out_ptrs = ptr4(feats), ptr4(edges_out)
+        call('gunet_unet_forward_static_f32', up.handle, C.byref(ws), 1, ptr(xb), C.byref(in_ptrs), 0, ptr(glob),
+             1, 1, ptr(out), C.byref(out_ptrs), ptr(global_out), stream)
+
+    # captured first: nothing but the plan's creation has touched the static buffer's symbol so far
+    cap_out = buffers()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    hip_graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(hip_graph, stream=side):
+        run(*cap_out, current_stream(xb.device))
+    hip_graph.replay()
+    torch.cuda.synchronize()
+    eager_out = buffers()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    run(*eager_out, current_stream(xb.device))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before       # no device allocation, none freed
+    assert torch.isfinite(eager_out[0]).all()
+    assert torch.equal(cap_out[0], eager_out[0]) and torch.equal(cap_out[2], eager_out[2])
+    for q in range(4):
+        assert torch.equal(cap_out[1][q], eager_out[1][q])
+
+
 def test_static_scratch_refuses_what_does_not_fit(oracle):
     import gunet_amd as amd
     from gunet_amd import _lib, plan
