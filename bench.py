@@ -83,14 +83,23 @@ def parse_args(argv=None):
 def launch_ranks(args):
     """Start `--gpus` ranks of this script with torch.distributed.run and relay their output.  The
     caller has not touched a GPU: a process that has initialised HIP must not be replaced or forked."""
+    if not args.stub:
+        import torch
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU runtime
+        if have < args.gpus:
+            sys.stderr.write(f'bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) '
+                             f'(torch.cuda.device_count()); nothing was started\n')
+            return 2
     port = args.master_port
     if not port:
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0))
             port = s.getsockname()[1]
     env = dict(os.environ)
-    # this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's buffer
-    # registration fails with `hipIpcGetMemHandle: invalid argument`
+    # The image this runs in exports HSA_ENABLE_IPC_MODE_LEGACY=0 and documents why: the pool's host
+    # driver only supports dmabuf IPC, and with the legacy mode RCCL's buffer sharing fails with
+    # `hipIpcGetMemHandle: invalid argument`.  That is the image's statement, not a measurement made
+    # here; the default only fills the variable in for an environment that lost it.
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -168,6 +177,67 @@ def timed_steps(step, drain, args, ranks):
     ranks.sync()
     ranks.barrier()
     return ranks.max_over_ranks(time.perf_counter() - t0)
+
+
+class PhaseClock:
+    """Where a multi-rank step spends its time, per rank: marks on the compute stream (device
+    events on a GPU, host clock on the CPU rehearsal) at the start of a step, after the forward and
+    after the exchange was posted.  `forward` is the device time of the forward; `exchange` is what
+    the step spends on the exchange on top of it: waiting for the transfers of two steps ago that
+    still hold the slot, staging this step's payload and queueing the collectives.  Steps before
+    `reset()` (the warm-up) are dropped."""
+
+    def __init__(self, dev):
+        self.cuda = dev.type == 'cuda'
+        self.marks = []
+
+    def _now(self):
+        if not self.cuda:
+            return time.perf_counter()
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def reset(self):
+        self.marks = []
+
+    def start(self):
+        self.marks.append([self._now()])
+
+    def mark(self):
+        self.marks[-1].append(self._now())
+
+    def summary(self):
+        """(forward_ms, exchange_ms) averaged over the recorded steps; call after a device sync."""
+        fw = ex = 0.0
+        done = [m for m in self.marks if len(m) == 3]
+        for a, b, c in done:
+            if self.cuda:
+                fw += a.elapsed_time(b)
+                ex += b.elapsed_time(c)
+            else:
+                fw += (b - a) * 1e3
+                ex += (c - b) * 1e3
+        n = max(1, len(done))
+        return fw / n, ex / n
+
+
+def multi_rank_report(args, ranks, clock, exchange, forward_only, payload_bytes):
+    """For more than one rank: where the timed steps spent their time (maximum over the ranks of each
+    rank's per-step averages), what a rank ships per step, and the same number of steps timed once more
+    without the exchange -- so a curve that bends says whether the forward or the exchange bent it.
+    Every rank must call this (it times steps between barriers).  {} for a single rank."""
+    if ranks.world == 1:
+        return {}
+    ranks.sync()
+    forward_ms, exchange_ms = clock.summary()
+    out = {'forward_ms': ranks.max_over_ranks(forward_ms), 'exchange_wait_ms': ranks.max_over_ranks(exchange_ms),
+           'payload_MB_per_rank_and_step': payload_bytes / 1e6}
+    if exchange is not None:
+        bare = timed_steps(forward_only, lambda: None, args, ranks)
+        out['ms_per_step_without_exchange'] = bare / args.steps * 1e3
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -344,17 +414,24 @@ def run_model(args, ranks):
             return ids.expand(B, 7, 96).contiguous()
         y = forward()
         exchange = sharding.StepExchange(y, rotate=True)
+        clock = PhaseClock(dev)
 
         def step(i):
+            clock.start()
             y = forward()
+            clock.mark()
             if world > 1:
                 exchange.post(i, y, torch.tensor([float(y.sum()), float(B)], dtype=torch.float64))
+            clock.mark()
             return y
         elapsed = timed_steps(step, exchange.drain, args, ranks)
+        clock.marks = clock.marks[args.warmup:]
+        phases = multi_rank_report(args, ranks, clock, exchange, lambda i: forward(), int(y.numel() * y.element_size()))
         seen = ranks.ranks_seen()
         if rank == 0:
             res = base_result(args, ranks, world * B * args.steps / elapsed, 'samples/s', elapsed)
             res.update({'stub': True, 'ranks_seen': seen, 'config': {'workload': 'stub forward (CPU rehearsal)'}})
+            res.update(phases)
             last = args.steps - 1
             if world > 1 and exchange.collector[last & 1] == 0:
                 res['gathered_sample_order'] = [int(v) for v in exchange.gathered[last & 1][:, :, 0, 0].reshape(-1).tolist()]
@@ -430,17 +507,25 @@ def run_model(args, ranks):
             exchange.post(i, payload(y), torch.zeros(2, dtype=torch.float64, device=dev))
         exchange.drain()
 
+    clock = PhaseClock(dev)
+
     def step(i):
+        clock.start()
         y = forward()
+        clock.mark()
         if world > 1 and exchange is not None:
             m = torch.stack((y.sum(dtype=torch.float64), torch.tensor(float(y.shape[0]), dtype=torch.float64, device=dev)))
             exchange.post(i, payload(y), m)
+        clock.mark()
         return y
 
     drain = exchange.drain if exchange is not None else (lambda: None)
     elapsed = timed_steps(step, drain, args, ranks)
+    clock.marks = clock.marks[args.warmup:]
     samples_per_s = world * B * args.steps / elapsed
     y = forward()
+    phases = multi_rank_report(args, ranks, clock, exchange, lambda i: forward(),
+                               0 if exchange is None else int(payload(y).numel() * payload(y).element_size()))
     seen = ranks.ranks_seen()
 
     prof = None if args.no_profile else profile_pass(lambda i: forward(), args.steps, ranks)
@@ -474,6 +559,7 @@ def run_model(args, ranks):
     result = base_result(args, ranks, samples_per_s, 'samples/s', elapsed)
     payload_bytes = 0 if world == 1 or exchange is None else int(payload(y).numel() * payload(y).element_size())
     result['ranks_seen'] = seen
+    result.update(phases)
     result['config'] = {
         'workload': (f'full GraphUNet fwd, checkpoint shapes (12x8-ch in, 12x8-ch out, width {args.min_units}, depth 3), '
                      f'one {args.height}x{args.width} ' + ('dense grid' if args.dense else f'road graph (density {args.density}, seed 0)')
@@ -803,12 +889,17 @@ def run_cities(args, ranks):
             metrics[:2] += sums.sum(dim=(0, 2))
             metrics[2] += float(len(ids) * d['n'] * 96)
 
+    clock = PhaseClock(dev)
+
     def step(i):
+        clock.start()
         forward_all()
+        clock.mark()
         if world > 1:
             if args.gather != 'none':
                 sharding.gather_rows(flat, dst=i % world, counts=counts, out=gathered[0])
             ranks.dist.all_reduce(metrics)
+        clock.mark()
 
     t0 = time.perf_counter()
     forward_all()
@@ -818,6 +909,9 @@ def run_cities(args, ranks):
         for dst in range(world):
             sharding.gather_rows(flat, dst=dst, counts=counts, out=gathered[0])
     elapsed = timed_steps(step, lambda: None, args, ranks)
+    clock.marks = clock.marks[args.warmup:]
+    phases = multi_rank_report(args, ranks, clock, True if args.gather != 'none' else None, lambda i: forward_all(),
+                               int(flat.numel() * flat.element_size()))
 
     # one untimed gather to rank 0, read back: the order in which the samples arrive
     forward_all()
@@ -838,6 +932,7 @@ def run_cities(args, ranks):
     n_of = (lambda c: stub_nodes[c]) if args.stub else None
     result = base_result(args, ranks, args.samples * args.steps / elapsed, 'samples/s', elapsed, scaling='strong')
     result['ranks_seen'] = seen
+    result.update(phases)
     result['samples_per_rank'] = [len(part) for part in all_mine]
     result['cities_per_rank'] = [sorted({sample_cities[i] for i in part}) for part in all_mine]
     result['gathered_rows'] = int(final.shape[0])

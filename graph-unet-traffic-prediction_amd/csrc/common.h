@@ -130,6 +130,19 @@ __device__ __forceinline__ void buffer_store_f1(BufferRsrc rs, uint32_t lane_off
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, lane_off, uniform_off, 0);
 }
 
+// A 16-byte LDS load the compiler may neither merge with its neighbours nor cut into pieces (one
+// ds_read_b128).  `p` must be 16-byte aligned.  Used where a wave picks up row-wise what its lanes
+// stored column-wise: left to itself hipcc (ROCm 7.2) cut two adjacent float4 loads that feed a bf16
+// packing into ds_read_b96 + ds_read2_b32 + ds_read_b32 pieces, and on gfx950 the first two words of
+// such a ds_read_b96 then came back as zeros once in some tens of launches (always for lanes 12-15 of
+// a 16-lane group, second half of a tile); waiting for the stores first did not change that, single
+// ds_read_b128 loads did.
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_load_f4(const float* p) {
+  const f32x4n v = *reinterpret_cast<const volatile f32x4n*>(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // The ReLU of the matrix kernels' epilogues as one instruction: the maximum with 0 (a NaN comes
 // out as 0, as from fmaxf; TensorFlow's ReLU hands a NaN on).  fmaxf() would first canonicalise the
 // accumulator with a second instruction.
@@ -179,10 +192,17 @@ int csr_from_keys(const int32_t* keys, int key_stride, int key_offset, int64_t n
 constexpr int kGnSkipPrologue = 1;
 constexpr int kGnSkipGlobalUpdate = 2;
 constexpr int kGnEdgesShared = 4;   // edges[q] is one [E_q, f_e] tensor for all samples
+// bf16 storage (the whole-model forward in GUNET_MATMUL_BF16 mode; 128-wide layers on graphs with an
+// in-edge table): x, x_skip, x_out, edges and edges_out hold bf16 although the parameters are typed
+// float*, and so do the layer's node embeddings in the workspace.
+constexpr int kGnStore16 = 8;
+constexpr int kGnEdgesIn32 = 16;    // with kGnStore16: edges[q] is float32 after all (the model's 16-wide input features)
+// with kGnStore16, gn_layer_run's edges_out32[q] (may be null) receive a float32 copy of the messages
 int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch, const float* x,
                  const float* x_skip, int32_t c_skip, const float* const edges[4], const float* global_in,
                  int32_t activation, float* x_out, float* const edges_out[4], float* global_out, void* workspace,
-                 size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream);
+                 size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream,
+                 float* const edges_out32[4] = nullptr);
 int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w, int32_t batch,
                     const float* x, const float* global_in, int32_t activation, float* x_out, float* global_out,
                     void* workspace, size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream);
@@ -196,8 +216,9 @@ int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int
 
 // Up to five row-wise segment maxima (src[i] [B, n_src[i], width[i]] -> out[i] [B, n_seg[i], width[i]]
 // over the CSR rowptr[i] / perm[i]) in one launch: the node and edge features of a 2x2 pooling step.
+// bf16 = true: src and out hold bf16 (the pointers are really __bf16*), widths count bf16 columns.
 int pool_max_multi(int n_jobs, const float* const* src, const int64_t* n_src, const int* width,
                    const int32_t* const* rowptr, const int32_t* const* perm, const int64_t* n_seg, float* const* out,
-                   int32_t batch, hipStream_t stream);
+                   int32_t batch, hipStream_t stream, bool bf16 = false);
 
 }  // namespace gunet

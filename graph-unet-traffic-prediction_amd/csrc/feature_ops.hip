@@ -654,6 +654,341 @@ __global__ __launch_bounds__(kThreads) void k_edge_mlp(EdgeArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- bf16-storage forms
+//
+// The whole-model forward in GUNET_MATMUL_BF16 mode keeps its intermediates -- node features, node
+// embeddings, messages -- in bf16 (the bf16 matrix instruction rounds its operands to bf16 anyway; a
+// tensor stored in bf16 carries the same rounding and half the bytes).  Accumulation, biases,
+// activations and column sums stay float32 / float64.  These kernels run at the speed of their memory
+// traffic: the matrix work is 16 times cheaper than in float32.
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4v pack_bf16x8(float4 lo, float4 hi) {
+  bf16x8 pk;
+  pk[0] = static_cast<__bf16>(lo.x); pk[1] = static_cast<__bf16>(lo.y);
+  pk[2] = static_cast<__bf16>(lo.z); pk[3] = static_cast<__bf16>(lo.w);
+  pk[4] = static_cast<__bf16>(hi.x); pk[5] = static_cast<__bf16>(hi.y);
+  pk[6] = static_cast<__bf16>(hi.z); pk[7] = static_cast<__bf16>(hi.w);
+  return __builtin_bit_cast(u32x4v, pk);
+}
+
+struct Edge16Args {
+  const int32_t* edge_index[4];
+  const void* efeat[4];     // FE = 32: bf16 [B, E_q, 32]; FE = 16: float32 [B, E_q, 16] ([E_q, 16] with ef_shared)
+  int ef_shared;
+  const float* edge_w[4];   // [f_e + 3u, u] float32 (rounded to bf16 on their way into registers)
+  __bf16* out[4];           // [B, E_q, 32]
+  float* out32[4];          // float32 copy of the same messages, [B, E_q, 32], or null
+  int n_edges[4];
+  int n_nodes;
+  int f_e;                  // rows of the weight matrix in front of the sender block
+  const __bf16* xq;         // [B, N, 128] node embeddings, direction q in columns 32q .. 32q+31
+  const float* ebias;       // [B, 4, 32]
+  double* partial;          // [B, 4, gridDim.x, 32] column sums of the (unscaled) messages
+  int relu;
+  float out_scale;
+};
+
+constexpr int kStageLd = 36;   // floats per staged row: 16-byte aligned rows, half-waves on different banks
+
+// Edge MLP on v_mfma_f32_32x32x16_bf16, 32 edges per wave step: the operand row of edge e is
+// [edge features | embedding of the sender | embedding of the receiver] in bf16, each lane's 8
+// consecutive k of a 16-wide k step one 16-byte load that is the MFMA operand as it stands.  The
+// weights live in registers (one bf16x8 fragment per k step).  FE: 32 = bf16 features (the messages
+// of the layer before), 16 = float32 features (the model's input edge features, rounded on the fly),
+// 0 = none.  Rows of group g + 1 and indices of group g + 2 are in flight behind the work of group g.
+template <int FE, bool SENDER_ONLY>
+struct Edge16Rows {
+  static constexpr int KS_F = FE == 32 ? 2 : (FE == 16 ? 1 : 0);
+  static constexpr int KS = KS_F + (SENDER_ONLY ? 2 : 4);
+  u32x4v v[KS];
+  float4 f[FE == 16 ? 2 : 1];   // float32 features wait here and are rounded when they are used
+};
+
+template <int FE, bool SENDER_ONLY, int EG>
+__global__ __launch_bounds__(kThreads) void k_edge_mlp16(Edge16Args a) {
+  using Rows = Edge16Rows<FE, SENDER_ONLY>;
+  constexpr int KS_F = Rows::KS_F, KS = Rows::KS;
+  __shared__ __attribute__((aligned(16))) float Stage[4][32 * kStageLd];
+  __shared__ double red[4 * 32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int q = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int n_edges = a.n_edges[q];
+  const int64_t block_base = static_cast<int64_t>(blockIdx.x) * edges_per_block(EG);
+  double colsum = 0.0;
+
+  if (block_base < n_edges) {   // uniform over the workgroup
+    bf16x8 wf[KS];
+    {
+      const float* w = a.edge_w[q];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int r0 = (s < KS_F ? 16 * s : a.f_e + 16 * (s - KS_F)) + 8 * lh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[s][j] = static_cast<__bf16>(w[(r0 + j) * 32 + li]);
+      }
+    }
+    const float bias = a.ebias[(b * 4 + q) * 32 + li];
+    const int2* ei = reinterpret_cast<const int2*>(a.edge_index[q]);
+    const __bf16* xq = a.xq + b * a.n_nodes * static_cast<int64_t>(128) + 32 * q;
+    const char* ef = static_cast<const char*>(a.efeat[q]);
+    if (FE != 0 && !a.ef_shared) ef += b * n_edges * static_cast<int64_t>(64);   // 32 bf16 or 16 floats per edge
+    __bf16* out = a.out[q] + b * n_edges * static_cast<int64_t>(32);
+    float* out32 = a.out32[q] ? a.out32[q] + b * n_edges * static_cast<int64_t>(32) : nullptr;
+    float* st = Stage[wave];
+    const int64_t wave_base = block_base + static_cast<int64_t>(wave) * EG * 32;
+    auto edge_of = [&](int grp) {
+      const int64_t e = wave_base + grp * 32 + li;
+      return e < n_edges ? e : static_cast<int64_t>(n_edges) - 1;   // clamped lanes are masked at the store
+    };
+    auto gather = [&](int64_t e, int2 sr, Rows& rows) {
+      if constexpr (FE == 32) {
+        const u32x4v* pf = reinterpret_cast<const u32x4v*>(ef + e * 64) + lh;
+        rows.v[0] = pf[0];
+        rows.v[1] = pf[2];
+      }
+      if constexpr (FE == 16) {
+        const float4* pf = reinterpret_cast<const float4*>(ef + e * 64) + 2 * lh;
+        rows.f[0] = pf[0];
+        rows.f[1] = pf[1];
+      }
+      const u32x4v* ps = reinterpret_cast<const u32x4v*>(xq + static_cast<int64_t>(sr.x) * 128) + lh;
+      rows.v[KS_F] = ps[0];
+      rows.v[KS_F + 1] = ps[2];
+      if constexpr (!SENDER_ONLY) {
+        const u32x4v* pr = reinterpret_cast<const u32x4v*>(xq + static_cast<int64_t>(sr.y) * 128) + lh;
+        rows.v[KS_F + 2] = pr[0];
+        rows.v[KS_F + 3] = pr[2];
+      }
+    };
+    auto multiply = [&](auto full_tag, int64_t e0, Rows& cur) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      if constexpr (FE == 16) cur.v[0] = pack_bf16x8(cur.f[0], cur.f[1]);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.v[s]), wf[s], acc, 0, 0, 0);
+      float gs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = activate(acc[r] + bias, a.relu);
+        if (FULL || e0 + row < n_edges) gs += v;
+        st[row * kStageLd + li] = v * a.out_scale;
+      }
+      gs += __shfl_xor(gs, 32);
+      colsum += static_cast<double>(gs);
+      // the 32 x 32 tile leaves row-wise: the group's bf16 rows are 2 KiB of consecutive memory
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + (lane >> 2), c8 = 8 * (lane & 3);
+        const float4 v0 = lds_load_f4(&st[row * kStageLd + c8]);
+        const float4 v1 = lds_load_f4(&st[row * kStageLd + c8 + 4]);
+        if (FULL || e0 + row < n_edges)
+          *reinterpret_cast<u32x4v*>(out + (e0 + row) * 32 + c8) = pack_bf16x8(v0, v1);
+      }
+      if (out32 != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * i + (lane >> 3), c4 = 4 * (lane & 7);
+          const float4 v = lds_load_f4(&st[row * kStageLd + c4]);
+          if (FULL || e0 + row < n_edges) *reinterpret_cast<float4*>(out32 + (e0 + row) * 32 + c4) = v;
+        }
+      }
+    };
+    auto step = [&](auto full_tag, int grp, Rows& cur, Rows& nxt, int2& sr_nxt, int2& sr_nxt2) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      const int64_t e0 = wave_base + grp * 32;
+      if (grp + 1 < EG && (FULL || e0 + 32 < n_edges)) {
+        if (grp + 2 < EG) sr_nxt2 = ei[FULL ? e0 + 64 + li : edge_of(grp + 2)];
+        gather(FULL ? e0 + 32 + li : edge_of(grp + 1), sr_nxt, nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests above the work of this group
+      multiply(full_tag, e0, cur);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Rows r0, r1;
+    int2 sr_a, sr_b;
+    if (wave_base + EG * 32 <= n_edges) {
+      sr_a = ei[wave_base + 32 + li];
+      gather(wave_base + li, ei[wave_base + li], r0);
+#pragma unroll
+      for (int grp = 0; grp < EG; grp += 2) {
+        step(std::true_type{}, grp, r0, r1, sr_a, sr_b);
+        step(std::true_type{}, grp + 1, r1, r0, sr_b, sr_a);
+      }
+    } else if (wave_base < n_edges) {
+      sr_a = ei[edge_of(1)];
+      gather(edge_of(0), ei[edge_of(0)], r0);
+      for (int grp = 0; grp < EG && wave_base + grp * 32 < n_edges; grp += 2) {
+        step(std::false_type{}, grp, r0, r1, sr_a, sr_b);
+        if (wave_base + (grp + 1) * 32 < n_edges) step(std::false_type{}, grp + 1, r1, r0, sr_b, sr_a);
+      }
+    }
+  }
+  if (lh == 0) red[wave * 32 + li] = colsum;
+  __syncthreads();
+  if (tid < 32) {
+    const double s = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+    a.partial[((b * 4 + q) * gridDim.x + blockIdx.x) * 32 + tid] = s;
+  }
+}
+
+// The five segment maxima of a 2x2 pooling step on bf16 tensors (k_pool_max on 8 columns per
+// thread): a maximum of bf16 values is one of them, so pooling stays exact.
+__global__ void k_pool_max16(PoolJobs j) {
+  int job = 0;
+  while (job < kPoolJobs - 1 && blockIdx.x >= j.block_end[job]) ++job;
+  const unsigned block = blockIdx.x - (job > 0 ? j.block_end[job - 1] : 0u);
+  const int width = j.width[job], wv = width / 8;
+  const int64_t n_seg = j.n_seg[job];
+  const int64_t idx = static_cast<int64_t>(block) * blockDim.x + threadIdx.x;
+  if (idx >= n_seg * wv) return;
+  const int64_t seg = idx / wv;
+  const int c = static_cast<int>(idx % wv) * 8;
+  const int64_t b = blockIdx.y;
+  const __bf16* s = reinterpret_cast<const __bf16*>(j.src[job]) + b * j.n_src[job] * width + c;
+  const int32_t* rowptr = j.rowptr[job];
+  const int32_t* perm = j.perm[job];
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = -FLT_MAX;
+  for (int p = beg; p < end; p += 4) {   // a 2x2 cell has at most four members: all rows in flight at once
+    u32x4v v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pi = p + i < end ? p + i : beg;   // a repeated member does not change a maximum
+      v[i] = *reinterpret_cast<const u32x4v*>(s + static_cast<int64_t>(perm[pi]) * width);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[2 * k] = fmaxf(acc[2 * k], __builtin_bit_cast(float, v[i][k] << 16));
+        acc[2 * k + 1] = fmaxf(acc[2 * k + 1], __builtin_bit_cast(float, v[i][k] & 0xFFFF0000u));
+      }
+  }
+  // an empty segment's -FLT_MAX rounds to -infinity in bf16; every segment of a pooling plan has members
+  *reinterpret_cast<u32x4v*>(reinterpret_cast<__bf16*>(j.out[job]) + (b * n_seg + seg) * width + c) =
+      pack_bf16x8(make_float4(acc[0], acc[1], acc[2], acc[3]), make_float4(acc[4], acc[5], acc[6], acc[7]));
+}
+
+// Node MLP of the fine rows of an upsampling layer in bf16 storage: for each quadrant's edges
+// (parent -> fine node) one K = 32 product message[e] . W_q (32 x 128) + bias, activation, written
+// to the fine node's row (every fine node has exactly one incoming edge), and the column sums.
+struct Scatter16Args {
+  const __bf16* msg[4];        // [B, n_rows[q], 32]
+  const int32_t* recv[4];      // receiver of edge r at recv[q][2 * r]
+  int n_rows[4];
+  const float* w[4];           // [32, 128] float32, row stride 128
+  const float* bias;           // [B, 128]
+  __bf16* out;                 // [B, out_rows, 128]
+  int out_rows, row_sub;
+  double* colsum;              // [B, colsum_tiles, 128]
+  int colsum_tiles;
+  int colsum_tile0[4];
+  unsigned block_end[4];       // running total of the quadrants' workgroups
+  int gpw;                     // 32-row groups per wave
+  int relu;
+};
+
+__global__ __launch_bounds__(kThreads) void k_scatter_gemm16(Scatter16Args a) {
+  __shared__ __attribute__((aligned(16))) float Stage[4][32 * kStageLd];
+  __shared__ double red[4 * 128];
+  int q = 0;
+  while (q < 3 && blockIdx.x >= a.block_end[q]) ++q;
+  const int blk = static_cast<int>(blockIdx.x - (q > 0 ? a.block_end[q - 1] : 0u));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.y;
+  const int n_rows = a.n_rows[q];
+  bf16x8 wf[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) wf[s][n][jj] = static_cast<__bf16>(a.w[q][(16 * s + 8 * lh + jj) * 128 + 32 * n + li]);
+  float bias[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) bias[n] = a.bias[b * 128 + 32 * n + li];
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};
+  const __bf16* msg = a.msg[q] + b * n_rows * static_cast<int64_t>(32);
+  __bf16* out = a.out + b * a.out_rows * static_cast<int64_t>(128);
+  float* st = Stage[wave];
+  const int groups = (n_rows + 31) / 32;
+  const int g_begin = (blk * 4 + wave) * a.gpw;
+  const int g_end = min(g_begin + a.gpw, groups);
+  auto row_of = [&](int grp) {
+    const int r = grp * 32 + li;
+    return r < n_rows ? r : n_rows - 1;
+  };
+  u32x4v cur[2], nxt[2];
+  int orow_cur = 0, orow_nxt = 0;
+  auto fetch = [&](int grp, u32x4v (&rows)[2], int& orow) {
+    const int r = row_of(grp);
+    const u32x4v* p = reinterpret_cast<const u32x4v*>(msg + static_cast<int64_t>(r) * 32) + lh;
+    rows[0] = p[0];
+    rows[1] = p[2];
+    orow = a.recv[q][2 * static_cast<int64_t>(r)] - a.row_sub;
+  };
+  if (g_begin < g_end) fetch(g_begin, cur, orow_cur);
+  for (int grp = g_begin; grp < g_end; ++grp) {
+    if (grp + 1 < g_end) fetch(grp + 1, nxt, orow_nxt);
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s]), wf[s][n], acc[n], 0, 0, 0);
+    }
+    const int row0 = grp * 32;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float gs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = activate(acc[n][r] + bias[n], a.relu);
+        if (row0 + row < n_rows) gs += v;
+        st[row * kStageLd + li] = v;
+      }
+      gs += __shfl_xor(gs, 32);
+      cs[n] += static_cast<double>(gs);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + (lane >> 2), c8 = 8 * (lane & 3);
+        const float4 v0 = lds_load_f4(&st[row * kStageLd + c8]);
+        const float4 v1 = lds_load_f4(&st[row * kStageLd + c8 + 4]);
+        const int orow = __shfl(orow_cur, row);
+        if (row0 + row < n_rows)
+          *reinterpret_cast<u32x4v*>(out + static_cast<int64_t>(orow) * 128 + 32 * n + c8) = pack_bf16x8(v0, v1);
+      }
+    }
+    cur[0] = nxt[0];
+    cur[1] = nxt[1];
+    orow_cur = orow_nxt;
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    if (lh == 0) red[wave * 128 + 32 * n + li] = cs[n];
+  __syncthreads();
+  if (tid < 128) {
+    const double s = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+    a.colsum[(b * a.colsum_tiles + a.colsum_tile0[q] + blk) * 128 + tid] = s;
+  }
+}
+
 struct AggArgs {
   const int32_t* rowptr[4];
   const int32_t* perm[4];
@@ -1297,16 +1632,77 @@ int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const gun
                  : launch_edge_mlp_ut<2>(a, chunks, vec_ok && all_feat, split.eg, grid, stream);
 }
 
+template <int FE, bool SO>
+int launch_edge_mlp16_inst(const Edge16Args& a, int eg, dim3 grid, hipStream_t stream) {
+  if (eg == kEdgeGroupsLarge)
+    k_edge_mlp16<FE, SO, kEdgeGroupsLarge><<<grid, kThreads, 0, stream>>>(a);
+  else
+    k_edge_mlp16<FE, SO, kEdgeGroupsSmall><<<grid, kThreads, 0, stream>>>(a);
+  GUNET_LAUNCH_CHECK();
+  return GUNET_OK;
+}
+
+// Edge MLP of a 128-wide layer in bf16 storage.  edges[q]: bf16 [B, E_q, 32] (f_e = 32), or float32
+// [B, E_q, 16] / [E_q, 16] (f_e = 16, edges_f32), or null for the sender-only form.
+int launch_edge_mlp16(Edge16Args& a, const gunet_quadgraph* graph, const gunet_gn_weights* w, const void* const edges[4],
+                      bool edges_f32, bool sender_only, int32_t batch, hipStream_t stream) {
+  const EdgeSplit split = edge_split(graph, w, batch);
+  GUNET_REQUIRE(split.eg != 0 && w->units == 128, "edge_mlp16: a 128-wide layer is needed");
+  double edges_total = 0.0;
+  for (int q = 0; q < 4; ++q) {
+    a.edge_index[q] = graph->edge_index[q];
+    a.efeat[q] = edges ? edges[q] : nullptr;
+    a.n_edges[q] = graph->n_edges[q];
+    edges_total += graph->n_edges[q];
+    GUNET_REQUIRE(sender_only || graph->n_edges[q] == 0 || a.efeat[q] != nullptr, "edge_mlp16: null edge features %d", q);
+    GUNET_REQUIRE(reinterpret_cast<uintptr_t>(a.efeat[q]) % 16 == 0 && reinterpret_cast<uintptr_t>(a.out[q]) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(a.out32[q]) % 16 == 0,
+                  "edge_mlp16: edge tensors must be 16-byte aligned");
+  }
+  a.f_e = w->f_e;
+  dim3 grid(static_cast<unsigned>(split.n_eblk), 4, static_cast<unsigned>(batch));
+  const int fe_used = sender_only ? 0 : w->f_e;
+  ProfScope prof(kProfEdgeMlp, stream, 2.0 * batch * edges_total * (fe_used + (sender_only ? 1 : 2) * 32.0) * 32.0);
+  if (sender_only) return launch_edge_mlp16_inst<0, true>(a, split.eg, grid, stream);
+  if (edges_f32) {
+    GUNET_REQUIRE(w->f_e == 16, "edge_mlp16: float32 edge features must be 16 wide, not %d", w->f_e);
+    return launch_edge_mlp16_inst<16, false>(a, split.eg, grid, stream);
+  }
+  GUNET_REQUIRE(w->f_e == 32, "edge_mlp16: bf16 edge features must be 32 wide, not %d", w->f_e);
+  return launch_edge_mlp16_inst<32, false>(a, split.eg, grid, stream);
+}
+
+// Workgroups per quadrant the scatter GEMM of an upsampling layer uses (= column-sum rows it writes
+// per quadrant) and the groups each of their waves walks.
+struct Scatter16Split {
+  int gpw, blocks[4], total;
+};
+
+Scatter16Split scatter16_split(const gunet_quadgraph* g, int64_t batch) {
+  Scatter16Split sp = {};
+  int max_groups = 1;
+  for (int q = 0; q < 4; ++q) max_groups = std::max(max_groups, (g->n_edges[q] + 31) / 32);
+  const int64_t target = std::min<int64_t>(128, std::max<int64_t>(16, 2 * device_cu_count() / (4 * std::max<int64_t>(1, batch))));
+  sp.gpw = static_cast<int>(std::max<int64_t>(1, ceil_div(max_groups, 4 * target)));
+  for (int q = 0; q < 4; ++q) {
+    sp.blocks[q] = static_cast<int>(ceil_div((g->n_edges[q] + 31) / 32, 4 * sp.gpw));
+    sp.total += sp.blocks[q];
+  }
+  return sp;
+}
+
 }  // namespace
 
 int pool_max_multi(int n_jobs, const float* const* src, const int64_t* n_src, const int* width,
                    const int32_t* const* rowptr, const int32_t* const* perm, const int64_t* n_seg, float* const* out,
-                   int32_t batch, hipStream_t stream) {
+                   int32_t batch, hipStream_t stream, bool bf16) {
   GUNET_REQUIRE(n_jobs >= 0 && n_jobs <= kPoolJobs, "pool_max_multi: %d jobs", n_jobs);
   bool vec = true;
+  const int per_thread = bf16 ? 8 : 4;   // 16 bytes either way
   for (int i = 0; i < n_jobs; ++i)
-    vec = vec && width[i] % 4 == 0 && reinterpret_cast<uintptr_t>(src[i]) % 16 == 0 &&
+    vec = vec && width[i] % per_thread == 0 && reinterpret_cast<uintptr_t>(src[i]) % 16 == 0 &&
           reinterpret_cast<uintptr_t>(out[i]) % 16 == 0;
+  GUNET_REQUIRE(vec || !bf16, "pool_max_multi: bf16 tensors need widths of 8 columns and 16-byte alignment");
   if (!vec) {
     for (int i = 0; i < n_jobs; ++i)
       GUNET_TRY(launch_segment_reduce<true>(src[i], n_src[i], width[i], rowptr[i], perm[i], n_seg[i], batch, 1.0f,
@@ -1325,16 +1721,19 @@ int pool_max_multi(int n_jobs, const float* const* src, const int64_t* n_src, co
       j.n_src[i] = n_src[i];
       j.n_seg[i] = n_seg[i];
       j.width[i] = width[i];
-      blocks += static_cast<unsigned>(ceil_div(n_seg[i] * (width[i] / 4), kThreads));
-      bytes += static_cast<double>(batch) * (4.0 * width[i] * (n_src[i] + n_seg[i]) + 4.0 * (n_src[i] + n_seg[i]));
+      blocks += static_cast<unsigned>(ceil_div(n_seg[i] * (width[i] / per_thread), kThreads));
+      bytes += static_cast<double>(batch) * ((bf16 ? 2.0 : 4.0) * width[i] * (n_src[i] + n_seg[i]) + 4.0 * (n_src[i] + n_seg[i]));
     } else {
-      j.width[i] = 4;
+      j.width[i] = per_thread;
     }
     j.block_end[i] = blocks;
   }
   if (blocks == 0) return GUNET_OK;
   ProfScope prof(kProfSegment, stream, bytes);
-  k_pool_max<<<dim3(blocks, static_cast<unsigned>(batch)), kThreads, 0, stream>>>(j);
+  if (bf16)
+    k_pool_max16<<<dim3(blocks, static_cast<unsigned>(batch)), kThreads, 0, stream>>>(j);
+  else
+    k_pool_max<<<dim3(blocks, static_cast<unsigned>(batch)), kThreads, 0, stream>>>(j);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
@@ -1419,9 +1818,15 @@ namespace gunet {
 int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_t batch, const float* x,
                  const float* x_skip, int32_t c_skip, const float* const edges[4], const float* global_in,
                  int32_t activation, float* x_out, float* const edges_out[4], float* global_out, void* workspace,
-                 size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream) {
+                 size_t workspace_bytes, int flags, int* n_partials_out, hipStream_t stream,
+                 float* const edges_out32[4]) {
   LayerWorkspace ws;
   GUNET_TRY(check_layer_args("gn_layer", graph, w, batch, activation, workspace, workspace_bytes, &ws));
+  const bool s16 = (flags & kGnStore16) != 0;
+  if (s16)
+    GUNET_REQUIRE(w->units == 128 && graph->in_table != nullptr && (w->c_in == 128 || w->c_in == 256) &&
+                      (c_skip == 0 || c_skip == 128),
+                  "gn_layer: bf16 storage needs a 128-wide layer on 128 or 256 input columns and a graph with an in-edge table");
   GUNET_REQUIRE(x && x_out && edges && edges_out, "gn_layer: null tensor");
   GUNET_REQUIRE(global_in || (flags & kGnSkipPrologue && flags & kGnSkipGlobalUpdate), "gn_layer: null global_in");
   GUNET_REQUIRE(global_out || (flags & kGnSkipGlobalUpdate), "gn_layer: null global_out");
@@ -1453,6 +1858,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     g.seg[1].ldw = u;
     g.n_rows = n;
     g.relu = relu;
+    g.a16 = g.o16 = s16;
     auto w_of = [&](int s, int col) {
       return w->node_emb_w[col / u] + (s == 0 ? 0 : static_cast<int64_t>(c_a) * u) + col % u;
     };
@@ -1460,7 +1866,23 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     GUNET_TRY(launch_gemm_columns_tile_bias(g, U, batch, b_of, ws.xq, w_of, ws.wpack, stream));
   }
 
-  {  // edge MLP + message column sums (hybrid_gnn.py:93-108)
+  if (s16) {  // edge MLP + message column sums on bf16 tensors
+    Edge16Args a = {};
+    for (int q = 0; q < 4; ++q) {
+      a.edge_w[q] = w->edge_w[q];
+      a.out[q] = reinterpret_cast<__bf16*>(edges_out[q]);
+      a.out32[q] = edges_out32 ? edges_out32[q] : nullptr;
+    }
+    a.n_nodes = n;
+    a.xq = reinterpret_cast<const __bf16*>(ws.xq);
+    a.ebias = ws.ebias;
+    a.partial = ws.epart;
+    a.relu = relu;
+    a.out_scale = 1.0f;
+    a.ef_shared = (flags & kGnEdgesShared) ? 1 : 0;
+    GUNET_TRY(launch_edge_mlp16(a, graph, w, reinterpret_cast<const void* const*>(edges), (flags & kGnEdgesIn32) != 0, false,
+                                batch, stream));
+  } else {  // edge MLP + message column sums (hybrid_gnn.py:93-108)
     EdgeArgs a = {};
     for (int q = 0; q < 4; ++q) {
       a.edge_w[q] = w->edge_w[q];
@@ -1500,6 +1922,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     for (int i = 0; i < s; ++i) g.seg[i].ldw = U;
     g.n_rows = n;
     g.relu = relu;
+    g.a16 = g.o16 = s16;
   }
   // With a per-node table of incoming edges the GEMM sums the messages while it loads them
   // (same order and scale as k_aggregate), and the aggregated tensor never exists.
@@ -1522,6 +1945,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     }
   }
 
+  GUNET_REQUIRE(!s16 || fused || n == 0, "gn_layer: bf16 storage needs the message-summing node MLP");
   if (n > 0 && !fused) {  // neighbour aggregation (hybrid_gnn.py:110-113)
     AggArgs a;
     for (int q = 0; q < 4; ++q) {
@@ -1582,6 +2006,8 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
   const int relu = activation == GUNET_ACT_RELU;
   const int U = w->units, u = U / 4, ut = U / 128;
   const LayerPtrs p = layer_ptrs(w);
+  const bool s16 = (flags & kGnStore16) != 0;
+  GUNET_REQUIRE(!s16 || (U == 128 && w->c_in == 128), "gn_upsample: bf16 storage needs a 128-wide layer on 128 input columns");
 
   // The layer input is [x ; 0]: rows n_coarse.. are zero, so their embedding is act(bias) for every
   // fine node; its product with the receiver rows of the edge kernel is folded into the edge bias.
@@ -1596,9 +2022,81 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
     g.seg[0].ldw = u;
     g.n_rows = n_coarse;
     g.relu = relu;
+    g.a16 = g.o16 = s16;
     auto w_of = [&](int, int col) { return w->node_emb_w[col / u] + col % u; };
     auto b_of = [&](int col) { return w->node_emb_b[col / u] ? w->node_emb_b[col / u] + col % u : nullptr; };
     GUNET_TRY(launch_gemm_columns_tile_bias(g, U, batch, b_of, ws.xq, w_of, ws.wpack, stream));
+  }
+
+  if (s16) {
+    // the same three steps on bf16 tensors: messages (scaled by 1/4) in ws.agg viewed as bf16
+    // [B, n_fine, 32]; column sums of the coarse rows; one scatter GEMM for the four quadrants
+    __bf16* msg16[4];
+    {
+      int64_t off = 0;
+      Edge16Args a = {};
+      for (int q = 0; q < 4; ++q) {
+        msg16[q] = reinterpret_cast<__bf16*>(ws.agg) + off;
+        off += static_cast<int64_t>(batch) * graph->n_edges[q] * u;
+        a.edge_w[q] = w->edge_w[q];
+        a.out[q] = msg16[q];
+      }
+      a.n_nodes = n_coarse;
+      a.xq = reinterpret_cast<const __bf16*>(ws.xq);
+      a.ebias = ws.ebias;
+      a.partial = ws.epart;
+      a.relu = relu;
+      a.out_scale = 1.0f / (3 + 1);
+      GUNET_TRY(launch_edge_mlp16(a, graph, w, nullptr, false, true, batch, stream));
+    }
+    GemmArgs gc = {};
+    gc.n_seg = 1;
+    gc.seg[0].a = x;
+    gc.seg[0].lda = w->c_in;
+    gc.seg[0].k = w->c_in;
+    gc.seg[0].ldw = U;
+    gc.n_rows = n_coarse;
+    gc.relu = relu;
+    gc.a16 = 1;
+    const int coarse_tiles = columns_colsum_rows(gc, U, batch, ws.wpack);
+    const Scatter16Split sp = scatter16_split(graph, batch);
+    const int tiles_total = coarse_tiles + sp.total;
+    GUNET_REQUIRE(tiles_total <= ws.n_nblk + 5, "gn_upsample: %d column-sum rows for a buffer of %d", tiles_total, ws.n_nblk + 5);
+    if (n_coarse > 0) {
+      gc.colsum_tiles = tiles_total;
+      auto w_of = [&](int, int col) { return w->node_w + col; };
+      GUNET_TRY(launch_gemm_columns(gc, U, batch, ws.gbias, U, nullptr, ws.npart, w_of, ws.wpack, stream));
+    }
+    if (sp.total > 0) {
+      Scatter16Args a = {};
+      unsigned blocks = 0;
+      int tile0 = coarse_tiles;
+      for (int q = 0; q < 4; ++q) {
+        a.msg[q] = msg16[q];
+        a.recv[q] = graph->n_edges[q] > 0 ? graph->edge_index[q] + 1 : nullptr;
+        a.n_rows[q] = graph->n_edges[q];
+        a.w[q] = w->node_w + static_cast<int64_t>(w->c_in + u * q) * U;
+        a.colsum_tile0[q] = tile0;
+        tile0 += sp.blocks[q];
+        blocks += static_cast<unsigned>(sp.blocks[q]);
+        a.block_end[q] = blocks;
+      }
+      a.bias = ws.gbias;
+      a.out = reinterpret_cast<__bf16*>(x_out);
+      a.out_rows = n_fine;
+      a.row_sub = n_coarse;
+      a.colsum = ws.npart;
+      a.colsum_tiles = tiles_total;
+      a.gpw = sp.gpw;
+      a.relu = relu;
+      ProfScope prof(kProfGemmTiled, stream, 2.0 * batch * n_fine * static_cast<double>(u) * U);
+      k_scatter_gemm16<<<dim3(blocks, static_cast<unsigned>(batch)), kThreads, 0, stream>>>(a);
+      GUNET_LAUNCH_CHECK();
+    }
+    if (n_partials_out) *n_partials_out = tiles_total;
+    if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
+    return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, w, batch).n_eblk, relu, batch, ws, global_out,
+                                stream);
   }
 
   // messages: every edge goes (coarse parent -> fine node); edge features are zero.  Stored

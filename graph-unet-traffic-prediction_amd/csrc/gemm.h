@@ -60,6 +60,11 @@ struct GemmArgs {
   int gather_rows[4];
   float gather_scale;
   int gather_fold;            // set by the launcher: gather_scale is a power of two and goes into the weight image
+  // bf16 storage (weights-resident kernels only): with a16 every operand segment and every gathered
+  // source tensor holds bf16 (the `a` / gather_src pointers are really const __bf16*, lda counts
+  // bf16 elements); with o16 `out` is written as bf16 (really a __bf16*, ldo counts bf16 elements).
+  int a16;
+  int o16;
 };
 
 constexpr int kBM = 128;
@@ -91,6 +96,12 @@ int gemm_colsum_rows(const GemmArgs& g, int nt, int64_t batch, const void* wpack
 // modes, may be null in GUNET_MATMUL_F32 mode); several problems of equal nt as one launch.
 int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stream);
 int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wpack, hipStream_t stream);
+
+// gunet_dense_forward_f32 with optional bf16 storage: a16 = x holds bf16 (k a multiple of 32), o16 =
+// out is written as bf16 (weights-resident kernels; see GemmArgs).
+int dense_run(const float* x, int64_t rows, int32_t k, const float* kernel, const float* bias, int32_t n_out,
+              int32_t activation, float* out, void* workspace, size_t workspace_bytes, int a16, int o16,
+              hipStream_t stream);
 
 // GEMM with U output columns as U/128 launches of 128 columns.  `w_of(s, col)` gives the weight
 // pointer of segment s for the 32-column tile starting at output column `col`.

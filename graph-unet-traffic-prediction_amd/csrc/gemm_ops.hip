@@ -296,11 +296,15 @@ struct ResidentTiles {
   uint32_t gather_bytes[4];   // size of each gathered source tensor (all samples)
 };
 
-template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
+// A16 = true (with BF16): the operand segments and the gathered source tensors are stored as bf16; a
+// lane's 8 consecutive k of a 16-wide k step are then one 16-byte load that is the MFMA operand as
+// it stands.  O16 = true: the output is stored as bf16 (rounded once, from the float32 result).
+template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false, bool A16 = false, bool O16 = false>
 __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(
     GemmArgs g, ResidentTiles tl, int groups_per_sample, int bps, int gpw) {
   static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
   static_assert(!RAGGED || (!GATHER && !BF16), "the ragged form is float32 without gathering");
+  static_assert(!A16 || BF16, "bf16 operands go to the bf16 matrix instruction");
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   constexpr int NX = GATHER ? NKT - 4 : NKT;   // K tiles read from the operand segments
   constexpr int BN = 32 * NT;
@@ -392,6 +396,12 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     // kt is a constant after unrolling: the tile's operand address and row stride are plain fields
     // of the argument block
     const BufferRsrc rs = buffer_of(tl.a[kt]);
+    if constexpr (A16) {   // 32 bf16 of the row: this lane's 8 k of either k step are 16 bytes
+      const uint32_t voff16 = arow * static_cast<uint32_t>(tl.lda[kt]) * 2u + 16u * static_cast<uint32_t>(lh);
+      a[0] = buffer_load_f4(rs, voff16, 0u);
+      a[1] = buffer_load_f4(rs, voff16 + 32u, 0u);
+      return;
+    }
     const uint32_t voff = (arow * static_cast<uint32_t>(tl.lda[kt]) + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
     if (RAGGED && kt == NKT - 1) {
       const int left = g.seg[0].k - kBK * (NKT - 1) - 4 * lh;   // floats of this lane's k phase left in the tile
@@ -415,10 +425,14 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 ap;
-        const float av[8] = {a[2 * s2].x,     a[2 * s2].y,     a[2 * s2].z,     a[2 * s2].w,
-                             a[2 * s2 + 1].x, a[2 * s2 + 1].y, a[2 * s2 + 1].z, a[2 * s2 + 1].w};
+        if constexpr (A16) {
+          ap = __builtin_bit_cast(bf16x8, a[s2]);
+        } else {
+          const float av[8] = {a[2 * s2].x,     a[2 * s2].y,     a[2 * s2].z,     a[2 * s2].w,
+                               a[2 * s2 + 1].x, a[2 * s2 + 1].y, a[2 * s2 + 1].z, a[2 * s2 + 1].w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ap[j] = static_cast<__bf16>(av[j]);
+          for (int j = 0; j < 8; ++j) ap[j] = static_cast<__bf16>(av[j]);
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const bf16x8 w = __builtin_bit_cast(bf16x8, wl[((2 * kt + s2) * NT + n) * 64]);
@@ -453,11 +467,14 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   const uint32_t ldo = static_cast<uint32_t>(g.ldo);
   const BufferRsrc out_rs = buffer_of(g.out);
   float* stage = res_smem + (BF16 ? 16 : 32) * NKT * BN + wave * (16 * 32);
-  const int srow = lane >> 3, scol = 4 * (lane & 7);
+  // float32 output: a lane picks up 4 columns of rows srow and 8 + srow of the staged 16; bf16
+  // output: 8 columns of one row (16 bytes either way)
+  const int srow = O16 ? lane >> 2 : lane >> 3, scol = O16 ? 8 * (lane & 3) : 4 * (lane & 7);
+  constexpr uint32_t kOutElem = O16 ? 2u : 4u;
   // this lane's pick-up position in the sample's first group, as a byte offset into the output
   const uint32_t out_lane_off =
       ((static_cast<uint32_t>(b) * static_cast<uint32_t>(g.out_rows) + static_cast<uint32_t>(srow)) * ldo +
-       static_cast<uint32_t>(g.out_col0 + col_shift + scol)) * 4u;
+       static_cast<uint32_t>(g.out_col0 + col_shift + scol)) * kOutElem;
   // Column sums: the float32 sum of each group's 32 rows (16 rows per lane in a fixed order, then
   // the two half-waves), added over the wave's run of groups in float64.
   float bias_v[NT];
@@ -479,7 +496,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   auto epilogue = [&](auto full_tag, auto relu_tag, int row0) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr bool RELU = decltype(relu_tag)::value;
-    const uint32_t group_off = static_cast<uint32_t>(row0) * ldo * 4u;   // uniform
+    const uint32_t group_off = static_cast<uint32_t>(row0) * ldo * kOutElem;   // uniform
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       float gs = 0.0f;   // this lane's 16 rows of column 32n + li
@@ -494,11 +511,24 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
           if (FULL || row0 + 16 * h + rl < g.n_rows) gs += v;
         }
         if (has_out) {
+          if constexpr (O16) {
+            const float4 v0 = lds_load_f4(&stage[srow * 32 + scol]);
+            const float4 v1 = lds_load_f4(&stage[srow * 32 + scol + 4]);
+            bf16x8 pk;
+            pk[0] = static_cast<__bf16>(v0.x); pk[1] = static_cast<__bf16>(v0.y);
+            pk[2] = static_cast<__bf16>(v0.z); pk[3] = static_cast<__bf16>(v0.w);
+            pk[4] = static_cast<__bf16>(v1.x); pk[5] = static_cast<__bf16>(v1.y);
+            pk[6] = static_cast<__bf16>(v1.z); pk[7] = static_cast<__bf16>(v1.w);
+            if (FULL || row0 + 16 * h + srow < g.n_rows)
+              buffer_store_f4(out_rs, out_lane_off, group_off + static_cast<uint32_t>(16 * h) * ldo * 2u + 64u * n,
+                              __builtin_bit_cast(float4, pk));
+          } else {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
-            if (FULL || row0 + 16 * h + 8 * i + srow < g.n_rows)
-              buffer_store_f4(out_rs, out_lane_off, group_off + static_cast<uint32_t>(16 * h + 8 * i) * ldo * 4u + 128u * n, v);
+            for (int i = 0; i < 2; ++i) {
+              const float4 v = *reinterpret_cast<const float4*>(&stage[(8 * i + srow) * 32 + scol]);
+              if (FULL || row0 + 16 * h + 8 * i + srow < g.n_rows)
+                buffer_store_f4(out_rs, out_lane_off, group_off + static_cast<uint32_t>(16 * h + 8 * i) * ldo * 4u + 128u * n, v);
+            }
           }
         }
       }
@@ -536,14 +566,26 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int id = tab_at(3 * q + j);
-      const uint32_t voff = id >= 0 ? ((base + static_cast<uint32_t>(id)) * 32u + kLaneFloats * static_cast<uint32_t>(lh)) * 4u : bytes;
+      if constexpr (A16) {   // a source row is 32 bf16: 16 bytes per k step and lane
+        const uint32_t voff = id >= 0 ? (base + static_cast<uint32_t>(id)) * 64u + 16u * static_cast<uint32_t>(lh) : bytes;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 v = buffer_load_f4(rs, voff + chunk_bytes(c), 0u);
-        if (j < 2)
-          gbuf[j][c] = v;
-        else
-          third[c] = v;
+        for (int c = 0; c < 2; ++c) {
+          const float4 v = buffer_load_f4(rs, voff + 32u * c, 0u);
+          if (j < 2)
+            gbuf[j][c] = v;
+          else
+            third[c] = v;
+        }
+      } else {
+        const uint32_t voff = id >= 0 ? ((base + static_cast<uint32_t>(id)) * 32u + kLaneFloats * static_cast<uint32_t>(lh)) * 4u : bytes;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 v = buffer_load_f4(rs, voff + chunk_bytes(c), 0u);
+          if (j < 2)
+            gbuf[j][c] = v;
+          else
+            third[c] = v;
+        }
       }
     }
   };
@@ -551,6 +593,29 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
   // power of two (gather_fold: scaling by it commutes exactly with every product)
   auto gather_reduce = [&](int q, const float4 (&third)[4], float4 (&a)[4]) {
     (void)q;
+    if constexpr (A16) {   // bf16 rows: widen, add in float32 in table order, round the sum once
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const u32x4 m0 = __builtin_bit_cast(u32x4, gbuf[0][c]), m1 = __builtin_bit_cast(u32x4, gbuf[1][c]),
+                    m2 = __builtin_bit_cast(u32x4, third[c]);
+        bf16x8 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float lo = (__builtin_bit_cast(float, m0[i] << 16) + __builtin_bit_cast(float, m1[i] << 16)) +
+                     __builtin_bit_cast(float, m2[i] << 16);
+          float hi = (__builtin_bit_cast(float, m0[i] & 0xFFFF0000u) + __builtin_bit_cast(float, m1[i] & 0xFFFF0000u)) +
+                     __builtin_bit_cast(float, m2[i] & 0xFFFF0000u);
+          if (!g.gather_fold) {
+            lo *= g.gather_scale;
+            hi *= g.gather_scale;
+          }
+          pk[2 * i] = static_cast<__bf16>(lo);
+          pk[2 * i + 1] = static_cast<__bf16>(hi);
+        }
+        a[c] = __builtin_bit_cast(float4, pk);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float4 s = gbuf[0][c];
@@ -622,7 +687,10 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     // Take delivery of the next group's first tile now, while only loads are outstanding: a wait
     // placed after the stores below would have to cover them as well (loads and stores share one
     // counter), and the wave would sit out its own write latency at the top of every group.
-    asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x), "+v"(a0[2].x), "+v"(a0[3].x));
+    if constexpr (A16)
+      asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x));
+    else
+      asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x), "+v"(a0[2].x), "+v"(a0[3].x));
     // The bias, added last as in the other GEMM kernels, by the matrix cores: one more product step
     // whose operands are a column of ones and the bias row (k = 0; zeros at k = 1), which adds
     // 1 * bias to every row of the tile in one rounding -- 4 instructions instead of 64 additions.
@@ -982,6 +1050,7 @@ inline int resident_block_waves(const GemmArgs& g, int nt) {
 
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
   if (g.row_map != nullptr || gathers_rows(g)) return false;
+  if (g.a16 || g.o16) return true;   // bf16 storage: these kernels only (launch_gemm_resident16 knows the shapes)
   if (mode_pieces(g_matmul_mode) > 1) return false;   // split-bf16 modes: tiled kernel only
   const bool bf16 = bf16_mode();
   const bool ragged = resident_ragged(g);   // one float32 segment of 97..127 columns, 128 output columns
@@ -1100,7 +1169,7 @@ int launch_tiled(int nt, bool group, dim3 grid, hipStream_t stream, const GemmAr
   return GUNET_OK;
 }
 
-template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false>
+template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false, bool A16 = false, bool O16 = false>
 int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   static std::atomic<bool> raised[64] = {};   // per device: the kernel's dynamic-LDS limit is raised
   const size_t lds = resident_lds_bytes(NT, NKT, BF16);
@@ -1108,7 +1177,7 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
   GUNET_HIP_TRY(hipGetDevice(&dev));
   GUNET_REQUIRE(dev >= 0 && dev < 64, "launch_gemm: device index %d", dev);
   if (!raised[dev].load(std::memory_order_acquire)) {   // two threads may both raise it: harmless
-    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED>),
+    GUNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED, A16, O16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(device_lds_limit())));
     raised[dev].store(true, std::memory_order_release);
@@ -1123,24 +1192,46 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
     const int n_plain = g.n_seg - (GATHER ? 1 : 0);   // the gathered segment is not read through the table
     for (int s = 0; s < n_plain; ++s)
       for (int k0 = 0; k0 < g.seg[s].k && t < kResMaxTiles; k0 += kBK, ++t) {
-        tl.a[t] = g.seg[s].a + k0;
+        tl.a[t] = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(g.seg[s].a) + k0) : g.seg[s].a + k0;
         tl.lda[t] = g.seg[s].lda;
       }
     GUNET_REQUIRE(t == (GATHER ? NKT - 4 : NKT), "launch_gemm: %d operand K tiles for a %d-tile kernel", t, NKT);
   }
   GemmArgs ga = g;
   if (GATHER) {
-    for (int q = 0; q < 4; ++q) tl.gather_bytes[q] = static_cast<uint32_t>(batch * g.gather_rows[q] * 128);
+    for (int q = 0; q < 4; ++q) tl.gather_bytes[q] = static_cast<uint32_t>(batch * g.gather_rows[q] * (A16 ? 64 : 128));
     int exponent = 0;
     ga.gather_fold = g.gather_scale > 0.0f && std::frexp(g.gather_scale, &exponent) == 0.5f;
   }
-  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED><<<blocks, 64 * kWaves, lds, stream>>>(ga, tl, sp.groups, sp.bps, sp.gpw);
+  k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED, A16, O16><<<blocks, 64 * kWaves, lds, stream>>>(ga, tl, sp.groups, sp.bps, sp.gpw);
   GUNET_LAUNCH_CHECK();
   return GUNET_OK;
 }
 
+// The launches of the bf16-storage forward: bf16 operands and / or bf16 output.
+int launch_gemm_resident16(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
+  const int kt = gemm_ktiles(g);
+  if (!g.a16) {   // float32 operand, bf16 result: the model's in_layer, in exact float32 products
+    if (resident_ragged(g) && nt == 4) return launch_resident_inst<4, 4, false, false, true, false, true>(g, batch, stream);
+    if (nt == 4 && kt == 4) return launch_resident_inst<4, 4, false, false, false, false, true>(g, batch, stream);
+  } else if (g.gather_table != nullptr) {
+    if (nt == 4 && kt == 8) return launch_resident_inst<4, 8, true, true, false, true, true>(g, batch, stream);
+    if (nt == 4 && kt == 12) return launch_resident_inst<4, 12, true, true, false, true, true>(g, batch, stream);
+  } else if (g.o16 || g.out == nullptr) {
+    if (nt == 4 && kt == 4) return launch_resident_inst<4, 4, false, true, false, true, true>(g, batch, stream);
+    if (nt == 4 && kt == 8) return launch_resident_inst<4, 8, false, true, false, true, true>(g, batch, stream);
+  } else {        // bf16 operand, float32 result: the model's out layer
+    if (nt == 3 && kt == 4) return launch_resident_inst<3, 4, false, true, false, true, false>(g, batch, stream);
+    if (nt == 4 && kt == 4) return launch_resident_inst<4, 4, false, true, false, true, false>(g, batch, stream);
+  }
+  set_error("launch_gemm: no bf16-storage kernel for %d column tiles, %d K tiles (a16 %d, o16 %d, gather %d)", nt, kt,
+            g.a16, g.o16, g.gather_table != nullptr);
+  return GUNET_ERR_UNSUPPORTED;
+}
+
 int launch_gemm_resident(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
   const int kt = gemm_ktiles(g);
+  if (g.a16 || g.o16) return launch_gemm_resident16(g, nt, batch, stream);
   if (bf16_mode()) {
     if (g.gather_table != nullptr)
       return kt == 8 ? launch_resident_inst<4, 8, true, true>(g, batch, stream)
@@ -1278,7 +1369,16 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
                             const float* bias, int32_t n_out, int32_t activation, float* out,
                             void* workspace, size_t workspace_bytes, gunet_stream_t stream_) {
   StreamDeviceGuard device_guard(as_stream(stream_));
-  hipStream_t stream = as_stream(stream_);
+  return dense_run(x, rows, k, kernel, bias, n_out, activation, out, workspace, workspace_bytes, 0, 0, as_stream(stream_));
+}
+
+}  // extern "C"
+
+namespace gunet {
+
+int dense_run(const float* x, int64_t rows, int32_t k, const float* kernel, const float* bias, int32_t n_out,
+              int32_t activation, float* out, void* workspace, size_t workspace_bytes, int a16, int o16,
+              hipStream_t stream) {
   GUNET_REQUIRE(rows >= 0 && k > 0 && n_out > 0, "dense_forward: bad shape");
   GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU,
                 "dense_forward: unknown activation %d", activation);
@@ -1287,6 +1387,7 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
   GUNET_REQUIRE(rows < INT32_MAX, "dense_forward: too many rows");
   const bool tiled = k % 4 == 0 && n_out % 32 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(kernel) % 16 == 0;
+  GUNET_REQUIRE(tiled || !(a16 || o16), "dense_forward: bf16 storage needs k %% 4 == 0, n_out %% 32 == 0 and 16-byte alignment");
   if (!tiled) {
     const unsigned grid = static_cast<unsigned>(ceil_div(rows * n_out, kThreads));
     ProfScope prof(kProfDenseNaive, stream);
@@ -1320,10 +1421,16 @@ int gunet_dense_forward_f32(const float* x, int64_t rows, int32_t k, const float
     g.ldo = n_out;
     g.out_col0 = col0;
     g.relu = activation == GUNET_ACT_RELU;
+    g.a16 = a16;
+    g.o16 = o16;
     GUNET_TRY(launch_gemm(g, nt, 1, workspace, stream));
   }
   return GUNET_OK;
 }
+
+}  // namespace gunet
+
+extern "C" {
 
 int gunet_set_matmul_mode(int mode) {
   GUNET_REQUIRE(mode == GUNET_MATMUL_F32 || mode == GUNET_MATMUL_SPLIT3 || mode == GUNET_MATMUL_SPLIT2 ||

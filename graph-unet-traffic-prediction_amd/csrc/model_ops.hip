@@ -10,7 +10,7 @@
 #include <new>
 #include <vector>
 
-#include "common.h"
+#include "gemm.h"
 
 struct gunet_plan {
   struct Level {   // one quadrant graph (a U-Net level, or an upsampling graph)
@@ -324,6 +324,31 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
                  int32_t out_activation, float* out, float* const edges_out[4], float* global_out, void* workspace,
                  size_t workspace_bytes, hipStream_t stream);
 
+// Whether a forward in GUNET_MATMUL_BF16 mode keeps its intermediates in bf16: the shipped shapes
+// (every block 128 wide, 16 input edge features, an in_layer of 97..128 input columns, up to 128
+// output columns in whole tiles) on a graph whose levels all have an in-edge table and whose
+// upsampling graphs have one parent edge per fine node.  Anything else runs the bf16 products on
+// float32 tensors.
+bool bf16_storage_ok(const gunet_plan* P, const gunet_unet_weights* w, int64_t batch) {
+  if (!bf16_mode()) return false;
+  const int D = P->depth;
+  // the kernels address a whole batch of a tensor with 32-bit byte offsets
+  if (batch * P->levels[0].n_nodes * 128 * 4 >= (int64_t{1} << 32)) return false;
+  for (int q = 0; q < 4; ++q)
+    if (batch * P->levels[0].n_edges[q] * 32 * 4 >= (int64_t{1} << 32) - 256) return false;
+  auto narrow = [](const gunet_gn_weights& g) { return g.units == 128; };
+  for (int l = 0; l < D; ++l)
+    if (!narrow(w->down[l]) || !narrow(w->up_sampling[l]) || !narrow(w->up_gcn[l][0]) || !narrow(w->up_gcn[l][1]) ||
+        !P->one_parent_edge[l])
+      return false;
+  if (!narrow(w->bottleneck[0]) || !narrow(w->bottleneck[1])) return false;
+  for (int l = 0; l <= D; ++l)
+    if (P->levels[l].n_nodes > 0 && P->levels[l].in_table == nullptr) return false;
+  if (w->down[0].c_in != 128 || w->down[0].f_e != 16) return false;
+  if (!(w->c_in == 128 || (w->c_in > 96 && w->c_in < 128 && w->c_in % 4 == 0))) return false;
+  return w->out_units % 32 == 0 && w->out_units >= 96 && w->out_units <= 128;
+}
+
 // Intermediates of gunet_unet_forward_static_f32: one array per GPU, alive from the loading of the
 // code object to the end of the process, shared by every call on that GPU.  In host code the
 // array's name is only a handle for hipGetSymbolAddress; the device address it yields (one per
@@ -540,10 +565,15 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
   const int64_t B = batch;
   int slot = 0;
   auto next_global = [&]() { return mb.globals + mb.global_slot * slot++; };
+  // GUNET_MATMUL_BF16 on the shipped shapes: every intermediate tensor (node features, node
+  // embeddings, messages; skip tensors included) is kept in bf16 in the first half of its buffer
+  const bool s16 = bf16_storage_ok(P, w, batch);
+  const int f16 = s16 ? kGnStore16 : 0;
+  const int in32 = s16 ? kGnEdgesIn32 : 0;   // layers that read the caller's float32 edge features
 
   // in_layer (graph_unet.py:37, :66): Dense with bias, no activation
-  GUNET_TRY(gunet_dense_forward_f32(x, B * P->levels[0].n_nodes, w->c_in, w->in_kernel, w->in_bias, w->down[0].c_in,
-                                    GUNET_ACT_LINEAR, mb.skip_x[0], mb.layer_ws, mb.layer_ws_bytes, stream));
+  GUNET_TRY(dense_run(x, B * P->levels[0].n_nodes, w->c_in, w->in_kernel, w->in_bias, w->down[0].c_in, GUNET_ACT_LINEAR,
+                      mb.skip_x[0], mb.layer_ws, mb.layer_ws_bytes, 0, s16, stream));
 
   // Consecutive GN layers are joined: the global update that ends one layer and the prologue that
   // starts the next (both one small workgroup per sample) run as one kernel, gn_bridge.  `pend` is
@@ -574,7 +604,7 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
     pend = {&L.qg, &gw, 0, cur_g, mb.skip_g[l + 1]};
     GUNET_TRY(gn_layer_run(&L.qg, &gw, batch, mb.skip_x[l], nullptr, 0, e_in, cur_g, activation, mb.tmp_x[0],
                            mb.tmp_e[0].q, nullptr, mb.layer_ws, mb.layer_ws_bytes,
-                           l == 0 ? (kGnSkipGlobalUpdate | shared0) : mid, &pend.n_partials, stream));
+                           (l == 0 ? (kGnSkipGlobalUpdate | shared0 | in32) : mid) | f16, &pend.n_partials, stream));
     cur_g = mb.skip_g[l + 1];
     {  // graph_pooling_2x2 (hybrid_gnn.py:427, :401): node features and the four edge-feature sets
       const float* src[5] = {mb.tmp_x[0]};
@@ -592,7 +622,7 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
         n_seg[1 + q] = C.n_edges[q];
         width[1 + q] = gw.units / 4;
       }
-      GUNET_TRY(pool_max_multi(5, src, n_src, width, rowptr, perm, n_seg, dst, batch, stream));
+      GUNET_TRY(pool_max_multi(5, src, n_src, width, rowptr, perm, n_seg, dst, batch, stream, s16));
     }
   }
 
@@ -606,7 +636,7 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
     GUNET_TRY(enter(graph, &w->bottleneck[i], 0, nullptr, 0, nullptr));
     pend = {graph, &w->bottleneck[i], 0, cur_g, g_out};
     GUNET_TRY(gn_layer_run(graph, &w->bottleneck[i], batch, cur_x, nullptr, 0, cur_e, cur_g, activation,
-                           mb.tmp_x[side], mb.tmp_e[side].q, nullptr, mb.layer_ws, mb.layer_ws_bytes, mid,
+                           mb.tmp_x[side], mb.tmp_e[side].q, nullptr, mb.layer_ws, mb.layer_ws_bytes, mid | f16,
                            &pend.n_partials, stream));
     cur_x = mb.tmp_x[side];
     cur_e = mb.tmp_e[side].q;
@@ -625,11 +655,12 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
     float* g_cat = next_global();   // [global | target global], hybrid_gnn.py:375
     float* g_up = next_global();
     const bool fast = P->one_parent_edge[l] && up.units <= 256;   // else the reference's literal route
+    GUNET_REQUIRE(fast || !s16, "unet_forward: bf16 storage on an upsampling level that needs the literal route");
     GUNET_TRY(enter(&P->ups[l].qg, &up, fast ? 1 : 0, target_g, target_width, g_cat));
     pend = {&P->ups[l].qg, &up, 0, g_cat, g_up};
     if (fast) {
       GUNET_TRY(gn_upsample_run(&P->ups[l].qg, static_cast<int32_t>(C.n_nodes), &up, batch, cur_x, g_cat, activation,
-                                mb.tmp_x[side], nullptr, mb.layer_ws, mb.layer_ws_bytes, mid, &pend.n_partials, stream));
+                                mb.tmp_x[side], nullptr, mb.layer_ws, mb.layer_ws_bytes, mid | f16, &pend.n_partials, stream));
     } else {   // hybrid_gnn.py:342-344, 373-377 as written: the layer on [x ; zeros] with zero edge features
       const int64_t n_all = C.n_nodes + L.n_nodes;
       GUNET_HIP_TRY(hipMemsetAsync(mb.up_in, 0, sizeof(float) * B * n_all * up.c_in, stream));
@@ -650,10 +681,13 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
       float* g_out = last && global_out ? global_out : next_global();
       float* const* e_out = mb.tmp_e[side].q;
       float* last_e[4];
-      if (last && edges_out) {
+      if (last && edges_out && !s16) {
         for (int q = 0; q < 4; ++q) last_e[q] = edges_out[q] ? edges_out[q] : mb.tmp_e[side].q[q];
         e_out = last_e;
       }
+      // bf16 storage: the messages go to the workspace in bf16 (the node MLP sums them from there) and,
+      // in the last layer, to the caller's tensors in float32 as well
+      float* const* e_out32 = (last && s16) ? edges_out : nullptr;
       const int c_skip = j == 0 ? gw.c_in - up.units : 0;   // concat(x, x_skip), hybrid_gnn.py:235
       GUNET_TRY(enter(&L.qg, &gw, 0, nullptr, 0, nullptr));
       pend = {&L.qg, &gw, 0, cur_g, g_out};
@@ -662,7 +696,8 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
       const int shared = (l == 0 && j == 0) ? shared0 : 0;
       GUNET_TRY(gn_layer_run(&L.qg, &gw, batch, cur_x, j == 0 ? mb.skip_x[l] : nullptr, c_skip, e_in, cur_g, activation,
                              mb.tmp_x[side], e_out, last ? g_out : nullptr, mb.layer_ws, mb.layer_ws_bytes,
-                             (last ? kGnSkipPrologue : mid) | shared, &pend.n_partials, stream));
+                             (last ? kGnSkipPrologue : mid) | shared | f16 | ((l == 0 && j == 0) ? in32 : 0),
+                             &pend.n_partials, stream, e_out32));
       cur_x = mb.tmp_x[side];
       e_in = e_out == last_e ? nullptr : mb.tmp_e[side].q;
       cur_g = g_out;
@@ -670,8 +705,8 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
     }
   }
   // out_model (:82): Dense without bias
-  return gunet_dense_forward_f32(cur_x, B * P->levels[0].n_nodes, final_width, w->out_kernel, w->out_bias, w->out_units,
-                                 out_activation, out, mb.layer_ws, mb.layer_ws_bytes, stream);
+  return dense_run(cur_x, B * P->levels[0].n_nodes, final_width, w->out_kernel, w->out_bias, w->out_units, out_activation,
+                   out, mb.layer_ws, mb.layer_ws_bytes, s16, 0, stream);
 }
 
 }  // namespace

@@ -110,8 +110,9 @@ int gunet_get_sender_receiver_f32(const float* x, int64_t n_nodes, int32_t width
 /* tf.math.unsorted_segment_max / _sum over rows (layers/hybrid_gnn.py:401,427,
  * 110).  src [B, n_src, width]; out [B, n_segments, width]; segments given as
  * CSR (rowptr, perm) from gunet_csr_from_keys.  Empty segment: -FLT_MAX (max)
- * or 0 (sum).  The sum adds rows front to back and multiplies by `scale`.  The maximum is fmaxf's:
- * a NaN among the members is dropped unless all are NaN (TensorFlow propagates it). */
+ * or 0 (sum).  The sum adds rows front to back and multiplies by `scale`.  The maximum is fmaxf's,
+ * started from -FLT_MAX: NaNs among the members are dropped, a segment of NaNs only gives -FLT_MAX
+ * (TensorFlow propagates a NaN). */
 int gunet_segment_max_f32(const float* src, int64_t n_src, int32_t width, const int32_t* rowptr,
                           const int32_t* perm, int64_t n_segments, int32_t batch, float* out,
                           gunet_stream_t stream);
@@ -276,8 +277,8 @@ int gunet_plan_upsampling(const gunet_plan* plan, int32_t level, gunet_quadgraph
  * edges[q] [B, E_lq, edge_width] over the fine edges that map to each pooled edge (self-loops
  * dropped).  Either half may be left out (x = x_out = NULL, or edges = edges_out = NULL).
  * Asynchronous on `stream`, allocates nothing.  Maxima are exact: bit-identical to the reference for
- * inputs without NaNs (a NaN among the members is dropped unless all are NaN, see
- * gunet_segment_max_f32; TensorFlow hands it on). */
+ * inputs without NaNs (NaNs among the members are dropped, see gunet_segment_max_f32; TensorFlow
+ * hands them on). */
 int gunet_plan_pool_features_f32(const gunet_plan* plan, int32_t level, int32_t batch, const float* x,
                                  int32_t width, const float* const edges[4], int32_t edge_width,
                                  float* x_out, float* const edges_out[4], gunet_stream_t stream);

@@ -38,15 +38,37 @@ def test_six_city_mode_world2_gathers_in_sharding_order():
     nodes = (11, 13, 17, 19, 23, 29)
     assert res['gathered_rows'] == sum(nodes[c] for c in cities)
     assert res['metric_count'] == 15.0 and res['scaling'] == 'strong' and res['steps'] == 3
+    _check_phase_fields(res)
+
+
+def _check_phase_fields(res):
+    """A multi-rank line says where its steps went: forward and exchange time per step, what a rank
+    ships per step, and the step time of the same run without the exchange."""
+    for key in ('forward_ms', 'exchange_wait_ms', 'payload_MB_per_rank_and_step', 'ms_per_step_without_exchange'):
+        assert key in res and res[key] >= 0.0, key
+    assert res['payload_MB_per_rank_and_step'] > 0.0
+    # the parts of a step cannot take longer than the step (measured on the same steps, per rank)
+    assert res['forward_ms'] + res['exchange_wait_ms'] <= 1.5 * res['ms_per_step'] + 1.0
 
 
 def test_default_mode_world2_and_world1():
     res = _json_line(_run('--gpus', '2'))
     assert res['n_gpus'] == 2 and len(res['ranks_seen']) == 2 and res['scaling'] == 'weak'
+    _check_phase_fields(res)
     # step 2 (the last of 3) is collected on rank 2 % 2 = 0: both ranks' batches, rank order
     assert res['gathered_sample_order'] == list(range(16))
     one = _json_line(_run('--gpus', '1', '--config', '4', '--samples', '7'))
     assert one['n_gpus'] == 1 and one['gathered_sample_order'] == one['expected_sample_order']
+    assert 'forward_ms' not in one                                  # a single rank exchanges nothing
+
+
+def test_more_gpus_than_the_node_has_is_refused_before_anything_starts():
+    import torch
+    have = torch.cuda.device_count()
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(have + 2), '--steps', '1', '--warmup', '0']
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=e)
+    assert proc.returncode == 2 and 'nothing was started' in proc.stderr
 
 
 def test_rank_count_must_match_gpus_flag():

@@ -412,10 +412,10 @@ def test_tiled_gemm_k_tail_reads_zeros_not_memory(amd):
     assert_close(got, want, TOL)
 
 
-def test_segment_max_nan_is_dropped_unless_alone(amd):
-    """gunet_segment_max_f32 takes fmaxf's maximum: a NaN among the members of a segment is dropped,
-    a segment of NaNs only gives NaN, an empty segment -FLT_MAX (TensorFlow's unsorted_segment_max
-    would hand the NaN on; the deviation is documented in the header)."""
+def test_segment_max_drops_nans(amd):
+    """gunet_segment_max_f32 takes fmaxf's maximum starting from -FLT_MAX: a NaN among the members of a
+    segment is dropped, a segment of NaNs only gives -FLT_MAX like an empty one (TensorFlow's
+    unsorted_segment_max would hand the NaN on; the deviation is documented in the header)."""
     from gunet_amd import _lib, plan
     nan = float('nan')
     src = torch.tensor([[1.0, nan, 3.0, -2.0], [nan, nan, 0.5, -7.0], [2.0, nan, nan, nan], [5.0, 6.0, 7.0, 8.0]], device='cuda')
@@ -426,7 +426,7 @@ def test_segment_max_nan_is_dropped_unless_alone(amd):
               _lib.current_stream(src.device))
     got = out.cpu().numpy()
     lowest = -np.finfo(np.float32).max
-    assert got[0, 0] == 2.0 and np.isnan(got[0, 1]) and got[0, 2] == 3.0 and got[0, 3] == -2.0
+    assert np.array_equal(got[0], np.array([2.0, lowest, 3.0, -2.0], np.float32))
     assert (got[1] == lowest).all()
     assert np.array_equal(got[2], [5.0, 6.0, 7.0, 8.0])
 
