@@ -303,7 +303,7 @@ template <int NT, int NKT, bool GATHER, bool BF16, bool RAGGED = false, bool A16
 __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThreads) void k_gemm_resident(
     GemmArgs g, ResidentTiles tl, int groups_per_sample, int bps, int gpw) {
   static_assert(!GATHER || (NKT >= 6 && NKT % 2 == 0), "the gathered segment is the last four K tiles");
-  static_assert(!RAGGED || (!GATHER && !BF16), "the ragged form is float32 without gathering");
+  static_assert(!RAGGED || (!GATHER && !A16), "the ragged form takes one float32 operand segment");
   static_assert(!A16 || BF16, "bf16 operands go to the bf16 matrix instruction");
   constexpr int kWaves = (GATHER && NT == 4) ? kResGatherWaves : kResWaves;
   constexpr int NX = GATHER ? NKT - 4 : NKT;   // K tiles read from the operand segments
@@ -345,11 +345,14 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
         if constexpr (BF16) {
           // thread -> (group of 8 k rows, column): 8 strided loads, one 16-byte LDS store
           uint4* img = reinterpret_cast<uint4*>(Ws);
-          for (int i = tid; i < sg.k * 4; i += kWaves * 64) {
+          const int k_img = RAGGED ? kBK * NKT : sg.k;   // ragged: the image's rows past k are zeros
+          for (int i = tid; i < k_img * 4; i += kWaves * 64) {
             const int kg = i >> 5, col = i & 31;
             bf16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = static_cast<__bf16>(wscale * w[static_cast<int64_t>(8 * kg + j) * sg.ldw + col]);
+            for (int j = 0; j < 8; ++j)
+              v[j] = static_cast<__bf16>((!RAGGED || 8 * kg + j < sg.k) ? wscale * w[static_cast<int64_t>(8 * kg + j) * sg.ldw + col]
+                                                                         : 0.0f);
             const int k0 = kbase + 8 * kg;   // = 16 * kstep + 8 * half
             img[((k0 >> 4) * NT + t) * 64 + ((k0 >> 3) & 1) * 32 + col] = __builtin_bit_cast(uint4, v);
           }
@@ -398,17 +401,19 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     const BufferRsrc rs = buffer_of(tl.a[kt]);
     if constexpr (A16) {   // 32 bf16 of the row: this lane's 8 k of either k step are 16 bytes
       const uint32_t voff16 = arow * static_cast<uint32_t>(tl.lda[kt]) * 2u + 16u * static_cast<uint32_t>(lh);
-      a[0] = buffer_load_f4(rs, voff16, 0u);
-      a[1] = buffer_load_f4(rs, voff16 + 32u, 0u);
+      const int at = 2 * (kt & 1);   // a buffer holds two K tiles (see load_step)
+      a[at] = buffer_load_f4(rs, voff16, 0u);
+      a[at + 1] = buffer_load_f4(rs, voff16 + 32u, 0u);
       return;
     }
     const uint32_t voff = (arow * static_cast<uint32_t>(tl.lda[kt]) + kLaneFloats * static_cast<uint32_t>(lh)) * 4u;
     if (RAGGED && kt == NKT - 1) {
-      const int left = g.seg[0].k - kBK * (NKT - 1) - 4 * lh;   // floats of this lane's k phase left in the tile
+      const int left = g.seg[0].k - kBK * (NKT - 1) - static_cast<int>(kLaneFloats) * lh;   // floats of this lane's k phase left in the tile
       const uint32_t first = arow * static_cast<uint32_t>(tl.lda[kt]) * 4u;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const bool ok = 8 * c < left;
+        // piece c starts 8c floats into the lane's k phase (float32 MFMA) or 16 (c / 2) + 4 (c % 2) (bf16)
+        const bool ok = (BF16 ? 16 * (c >> 1) + 4 * (c & 1) : 8 * c) < left;
         const float4 v = buffer_load_f4(rs, ok ? voff + chunk_bytes(c) : first, 0u);
         a[c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
       }
@@ -420,13 +425,14 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 
   f32x16 acc[NT];
   const float4* wl = reinterpret_cast<const float4*>(Ws) + lane;
-  auto multiply = [&](int kt, const float4 (&a)[4]) {
+  auto multiply = [&](int kt, const float4 (&a)[4], int at = 0) {
+    (void)at;
     if constexpr (BF16) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 ap;
         if constexpr (A16) {
-          ap = __builtin_bit_cast(bf16x8, a[s2]);
+          ap = __builtin_bit_cast(bf16x8, a[at + s2]);
         } else {
           const float av[8] = {a[2 * s2].x,     a[2 * s2].y,     a[2 * s2].z,     a[2 * s2].w,
                                a[2 * s2 + 1].x, a[2 * s2 + 1].y, a[2 * s2 + 1].z, a[2 * s2 + 1].w};
@@ -630,9 +636,24 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     }
   };
 
+  // A step of the K loop is one K tile, or two with bf16 operands: their tiles are half the bytes and
+  // their matrix work a sixteenth, so a wave must keep twice the K range in flight to cover the
+  // memory latency (the kernel then runs at the speed of its loads).
+  constexpr int TPB = A16 ? 2 : 1;
+  auto load_step = [&](uint32_t arow, int st, float4 (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < TPB; ++j) load_tile(arow, st * TPB + j, a);
+  };
+  auto multiply_step = [&](int st, const float4 (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < TPB; ++j) multiply(st * TPB + j, a, 2 * j);
+  };
+  constexpr int NXS = NX / TPB, NKS = NKT / TPB;   // steps over the operand segments / over all of K
+  static_assert(NX % (2 * TPB) == 0, "the K loop walks the operand tiles two steps at a time");
+
   uint32_t cur = lane_row(has_work ? grp : 0);
   float4 a0[4], a1[4];
-  if (has_work) load_tile(cur, 0, a0);
+  if (has_work) load_step(cur, 0, a0);
   while (has_work) {
     const bool has_next = grp + 1 < grp_end;
     const uint32_t nxt = lane_row(has_next ? grp + 1 : grp);   // a finished wave re-reads its own rows: harmless
@@ -643,17 +664,17 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
     if constexpr (GATHER) {
       load_table(grp);
 #pragma unroll
-      for (int kt = 0; kt < NX; kt += 2) {
-        load_tile(cur, kt + 1, a1);
+      for (int st = 0; st < NXS; st += 2) {
+        load_step(cur, st + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(kt, a0);
+        multiply_step(st, a0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < NX)
-          load_tile(cur, kt + 2, a0);
+        if (st + 2 < NXS)
+          load_step(cur, st + 2, a0);
         else
           gather_issue(0, a0);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(kt + 1, a1);
+        multiply_step(st + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -663,34 +684,31 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
         if (q < 3)
           gather_issue(q + 1, a0);
         else
-          load_tile(nxt, 0, a0);
+          load_step(nxt, 0, a0);
         __builtin_amdgcn_sched_barrier(0);
         multiply(NX + q, a1);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
-      for (int kt = 0; kt < NKT; kt += 2) {
-        load_tile(cur, kt + 1, a1);
+      for (int st = 0; st < NKS; st += 2) {
+        load_step(cur, st + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(kt, a0);
+        multiply_step(st, a0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < NKT)
-          load_tile(cur, kt + 2, a0);
+        if (st + 2 < NKS)
+          load_step(cur, st + 2, a0);
         else
-          load_tile(nxt, 0, a0);
+          load_step(nxt, 0, a0);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(kt + 1, a1);
+        multiply_step(st + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     // Take delivery of the next group's first tile now, while only loads are outstanding: a wait
     // placed after the stores below would have to cover them as well (loads and stores share one
     // counter), and the wave would sit out its own write latency at the top of every group.
-    if constexpr (A16)
-      asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x));
-    else
-      asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x), "+v"(a0[2].x), "+v"(a0[3].x));
+    asm volatile("" : "+v"(a0[0].x), "+v"(a0[1].x), "+v"(a0[2].x), "+v"(a0[3].x));
     // The bias, added last as in the other GEMM kernels, by the matrix cores: one more product step
     // whose operands are a column of ones and the bias row (k = 0; zeros at k = 1), which adds
     // 1 * bias to every row of the tile in one rounding -- 4 instructions instead of 64 additions.
@@ -1211,9 +1229,9 @@ int launch_resident_inst(const GemmArgs& g, int64_t batch, hipStream_t stream) {
 // The launches of the bf16-storage forward: bf16 operands and / or bf16 output.
 int launch_gemm_resident16(const GemmArgs& g, int nt, int64_t batch, hipStream_t stream) {
   const int kt = gemm_ktiles(g);
-  if (!g.a16) {   // float32 operand, bf16 result: the model's in_layer, in exact float32 products
-    if (resident_ragged(g) && nt == 4) return launch_resident_inst<4, 4, false, false, true, false, true>(g, batch, stream);
-    if (nt == 4 && kt == 4) return launch_resident_inst<4, 4, false, false, false, false, true>(g, batch, stream);
+  if (!g.a16) {   // float32 operand (rounded to bf16 on its way into the matrix cores), bf16 result: the model's in_layer
+    if (resident_ragged(g) && nt == 4) return launch_resident_inst<4, 4, false, true, true, false, true>(g, batch, stream);
+    if (nt == 4 && kt == 4) return launch_resident_inst<4, 4, false, true, false, false, true>(g, batch, stream);
   } else if (g.gather_table != nullptr) {
     if (nt == 4 && kt == 8) return launch_resident_inst<4, 8, true, true, false, true, true>(g, batch, stream);
     if (nt == 4 && kt == 12) return launch_resident_inst<4, 12, true, true, false, true, true>(g, batch, stream);
