@@ -300,6 +300,21 @@ def measured_traffic(kernel, args):
             'stale': wl.get('source_stamp') != source_stamp()}
 
 
+def measured_step_traffic(args):
+    """HBM bytes one step (forward) moves, summed over every feature kernel of the committed counter
+    passes of this workload (profiles/hbm_traffic_per_launch.json: `feature_MB_per_forward`), and whether
+    the library sources have changed since; None when the workload has no table."""
+    key = workload_key(args)
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic_per_launch.json')
+    if key is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        wl = json.load(f).get('workloads', {}).get(key)
+    if not wl or 'feature_MB_per_forward' not in wl:
+        return None
+    return {'bytes': wl['feature_MB_per_forward'] * 1e6, 'stale': wl.get('source_stamp') != source_stamp()}
+
+
 def roofline_from_profile(prof, args, workload):
     """The `roofline` object: the kernel class with the most device time, its algorithmic work as the
     library counted it for exactly those launches, over its summed HIP-event durations."""
@@ -375,7 +390,7 @@ def base_result(args, ranks, value, unit, elapsed, scaling='weak'):
             'n_gpus': ranks.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'split3': 'f32 (3xbf16-split operands, 6 bf16 MFMA products, f32 accumulate)',
-                      'split2': 'f32 storage, 2xbf16-split matmul', 'bf16': 'bf16 matmul, f32 storage/accumulate'}[args.matmul],
+                      'split2': 'f32 storage, 2xbf16-split matmul', 'bf16': 'bf16 matmul and intermediate storage, f32 accumulate'}[args.matmul],
             'data': 'synthetic'}
 
 
@@ -481,8 +496,17 @@ def run_model(args, ranks):
                  'global': glob_dev}
         return model.predict(x_dev, graph)
 
-    # first call builds (and caches) every plan of this city
-    torch.cuda.synchronize()
+    # the index plan of this city (all levels), built once and cached; timed on its own, twice: the very
+    # first build also pays the one-off set-up of the library's kernels and of its temporary-block cache
+    plan_ms = []
+    for _ in range(2):
+        gunet_amd.plan.clear_caches()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gunet_amd.plan.get_unet_plan(node_loc_dev, list(quads), 3)
+        torch.cuda.synchronize()
+        plan_ms.append((time.perf_counter() - t0) * 1e3)
+    # first forward: weight table, workspace allocation, first launch of every kernel
     t0 = time.perf_counter()
     y = forward()
     torch.cuda.synchronize()
@@ -531,7 +555,7 @@ def run_model(args, ranks):
     prof = None if args.no_profile else profile_pass(lambda i: forward(), args.steps, ranks)
 
     # ---- the bf16-operand mode (float32 storage and accumulation), reported beside the result --------
-    alt = None
+    alt, alt_samples = None, {}
     if world == 1 and args.matmul == 'f32' and not args.no_alt_modes and args.min_units <= 256:
         gunet_amd.set_matmul_mode('bf16')
         try:
@@ -545,8 +569,11 @@ def run_model(args, ranks):
             dt = time.perf_counter() - t0
             alt = {'bf16': {'value': B * 10 / dt, 'unit': 'samples/s', 'ms_per_step': dt / 10 * 1e3, 'steps': 10,
                             'rel_diff_vs_f32_run': float((y_alt - y).abs().max() / y.abs().max()),
-                            'note': 'same workload with gunet_set_matmul_mode(GUNET_MATMUL_BF16): GEMM operands rounded to '
-                                    'bf16 for v_mfma_f32_32x32x16_bf16, float32 accumulate and storage; tolerance 2e-2'}}
+                            'note': 'same workload with gunet_set_matmul_mode(GUNET_MATMUL_BF16): every product on '
+                                    'v_mfma_f32_32x32x16_bf16 (float32 accumulate), node features, node embeddings and '
+                                    'messages stored in bf16 between the kernels, inputs and outputs float32; tolerance 2e-2 '
+                                    'against the float32 CPU oracle'}}
+            alt_samples = {b: y_alt[b].cpu().numpy() for b, _, _ in firsts}
         finally:
             gunet_amd.set_matmul_mode('f32')
 
@@ -571,12 +598,20 @@ def run_model(args, ranks):
         'forward': 'one gunet_unet_forward_f32 call per step over a cached gunet_plan',
         'workspace_GB': (lambda w: None if w is None else w.numel() / 1e9)(
             gunet_amd.plan.model_workspace_of(dev)),
-        'plan': 'cached', 'plan_build_ms_first_call': first_call_ms, 'quadrant_partition_ms': partition_ms,
+        'plan': 'cached', 'plan_build_ms': plan_ms[1], 'plan_build_ms_very_first': plan_ms[0],
+        'first_forward_ms': first_call_ms, 'quadrant_partition_ms': partition_ms,
     }
     if work is not None:
         result['config'].update({'gflop_per_sample': work['total_flops'] / 1e9,
                                  'executed_gflop_per_sample': work['total_flops_executed'] / 1e9,
                                  'compulsory_GB_per_sample': work['compulsory_bytes'] / 1e9})
+        step_traffic = measured_step_traffic(args)
+        if step_traffic is not None:
+            # every feature kernel's measured HBM bytes per launch x its launches per forward, against the bytes a
+            # fully fused layer would have to move (inputs read once, outputs written once)
+            result['hbm_bytes_per_step_measured'] = step_traffic['bytes']
+            result['traffic_over_compulsory'] = step_traffic['bytes'] / (B * work['compulsory_bytes'])
+            result['hbm_bytes_per_step_stale'] = step_traffic['stale']
     if prof is not None:
         steps = args.steps
         result['kernels'] = kernel_table(prof, steps)
@@ -623,7 +658,7 @@ def run_model(args, ranks):
         result['alt_matmul_modes'] = alt
     if world == 1 and not args.no_cpu_baseline:
         O = oracle_module()
-        times, errs = [], []
+        times, errs, alt_errs = [], [], []
         for i in range(args.cpu_runs + 1):
             # every run times one single-sample forward (equal work); the samples rotate so that the
             # runs double as parity checks of the first, middle and last sample of the batch
@@ -636,6 +671,8 @@ def run_model(args, ranks):
                 times.append(dt)
             if i < len(firsts):
                 errs.append((b,) + parity(y[b].cpu().numpy(), y_cpu))
+                if b in alt_samples:
+                    alt_errs.append(parity(alt_samples[b], y_cpu)[0])
         med = float(np.median(times))
         result['cpu_baseline'] = {
             'value': 1.0 / med, 'unit': 'samples/s', 'cores': cpu_threads(), 'kind': 'port',
@@ -644,6 +681,9 @@ def run_model(args, ranks):
         result['parity_rel_err_vs_cpu'] = max(e[1] for e in errs)
         result['parity_elementwise_rel_err_vs_cpu'] = max(e[2] for e in errs)
         result['parity_samples_checked'] = sorted({e[0] for e in errs})
+        if alt_errs:
+            result['alt_matmul_modes']['bf16']['parity_rel_err_vs_cpu'] = max(alt_errs)
+            result['alt_matmul_modes']['bf16']['parity_samples_checked'] = sorted(alt_samples)
     print(json.dumps(result))
 
 

@@ -91,6 +91,7 @@ SIGNATURES = {
                                         C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'gunet_segment_sum_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    'gunet_release_temporaries': (C.c_int, []),
     'gunet_set_matmul_mode': (C.c_int, [C.c_int]),
     'gunet_get_matmul_mode': (C.c_int, []),
     'gunet_set_kernel_choice': (C.c_int, [C.c_int]),

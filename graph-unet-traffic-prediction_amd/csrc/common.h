@@ -39,22 +39,33 @@ void set_error(const char* fmt, ...);
     if (rc_ != GUNET_OK) return rc_;                                                     \
   } while (0)
 
-// Temporary device allocation owned by a plan function (freed on scope exit).
+// Temporary device memory of the plan functions comes from a small per-process cache of blocks
+// instead of a hipMalloc / hipFree pair per temporary (a hipFree synchronises the whole device; a
+// plan build makes some hundred temporaries).  A block is handed out again only to a request made
+// for the same device and stream it was last used on -- work queued on one stream runs in order,
+// so the new user cannot overtake the old one -- and the cache holds at most kTempCacheBytes.
+// The stream is the one of the innermost entry point running on this thread (StreamDeviceGuard).
+hipError_t temp_alloc(void** ptr, size_t bytes, size_t* granted);
+void temp_release(void* ptr, size_t granted);
+void temp_cache_clear();   // frees every cached block of every device
+hipStream_t& entry_stream();   // thread-local
+
+// Temporary device allocation owned by a plan function (back to the cache on scope exit).
 class DevBuf {
  public:
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() {
-    if (ptr_) (void)hipFree(ptr_);
+    if (ptr_) temp_release(ptr_, granted_);
   }
   hipError_t alloc(size_t bytes) {
     if (ptr_) {
-      (void)hipFree(ptr_);
+      temp_release(ptr_, granted_);
       ptr_ = nullptr;
     }
     if (bytes == 0) bytes = 16;
-    return hipMalloc(&ptr_, bytes);
+    return temp_alloc(&ptr_, bytes, &granted_);
   }
   template <typename T>
   T* as() const {
@@ -63,6 +74,7 @@ class DevBuf {
 
  private:
   void* ptr_ = nullptr;
+  size_t granted_ = 0;
 };
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -158,7 +170,8 @@ __device__ __forceinline__ float max_bare(float v, float floor) {
 // The null stream belongs to whatever device is current.
 class StreamDeviceGuard {
  public:
-  explicit StreamDeviceGuard(hipStream_t stream) {
+  explicit StreamDeviceGuard(hipStream_t stream) : outer_stream_(entry_stream()) {
+    entry_stream() = stream;
     int current = 0, wanted = 0;
     if (stream != nullptr && hipGetDevice(&current) == hipSuccess &&
         hipStreamGetDevice(stream, &wanted) == hipSuccess && wanted != current &&
@@ -166,6 +179,7 @@ class StreamDeviceGuard {
       previous_ = current;
   }
   ~StreamDeviceGuard() {
+    entry_stream() = outer_stream_;
     if (previous_ >= 0) (void)hipSetDevice(previous_);
   }
   StreamDeviceGuard(const StreamDeviceGuard&) = delete;
@@ -173,6 +187,7 @@ class StreamDeviceGuard {
 
  private:
   int previous_ = -1;
+  hipStream_t outer_stream_;
 };
 
 // Exclusive prefix sum of `n` int32 values into out[0..n] (n + 1 entries; out[n] = total).

@@ -3,6 +3,8 @@
 // upsampling edge lists.  Everything here is bit-exact integer work; results do not depend
 // on atomic arrival order (only integer counts, minima and maxima go through atomics).
 #include <climits>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -15,6 +17,89 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_error, sizeof(g_error), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------- cache of temporary blocks
+
+namespace {
+struct TempBlock {
+  void* ptr;
+  size_t bytes;
+  int device;
+  hipStream_t stream;
+};
+constexpr size_t kTempCacheBytes = size_t{256} << 20;
+std::mutex g_temp_lock;
+std::vector<TempBlock> g_temp_free;   // idle blocks, oldest first
+size_t g_temp_free_bytes = 0;
+}  // namespace
+
+hipStream_t& entry_stream() {
+  static thread_local hipStream_t stream = nullptr;
+  return stream;
+}
+
+hipError_t temp_alloc(void** ptr, size_t bytes, size_t* granted) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const hipStream_t stream = entry_stream();
+  {
+    std::lock_guard<std::mutex> hold(g_temp_lock);
+    int best = -1;
+    for (int i = 0; i < static_cast<int>(g_temp_free.size()); ++i) {
+      const TempBlock& b = g_temp_free[i];
+      if (b.device != dev || b.stream != stream || b.bytes < bytes || b.bytes > 4 * bytes + 4096) continue;
+      if (best < 0 || b.bytes < g_temp_free[best].bytes) best = i;
+    }
+    if (best >= 0) {
+      *ptr = g_temp_free[best].ptr;
+      *granted = g_temp_free[best].bytes;
+      g_temp_free_bytes -= g_temp_free[best].bytes;
+      g_temp_free.erase(g_temp_free.begin() + best);
+      return hipSuccess;
+    }
+  }
+  const size_t rounded = (bytes + 4095) / 4096 * 4096;
+  *granted = rounded;
+  return hipMalloc(ptr, rounded);
+}
+
+void temp_release(void* ptr, size_t granted) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::vector<void*> evicted;
+  {
+    std::lock_guard<std::mutex> hold(g_temp_lock);
+    if (granted > kTempCacheBytes / 2) {
+      evicted.push_back(ptr);
+    } else {
+      g_temp_free.push_back({ptr, granted, dev, entry_stream()});
+      g_temp_free_bytes += granted;
+      while (g_temp_free_bytes > kTempCacheBytes && !g_temp_free.empty()) {
+        if (g_temp_free.front().device != dev) break;   // another device's block: left to temp_cache_clear()
+        evicted.push_back(g_temp_free.front().ptr);
+        g_temp_free_bytes -= g_temp_free.front().bytes;
+        g_temp_free.erase(g_temp_free.begin());
+      }
+    }
+  }
+  for (void* p : evicted) (void)hipFree(p);   // synchronises the device: whatever still used the block is done
+}
+
+void temp_cache_clear() {
+  std::vector<TempBlock> all;
+  {
+    std::lock_guard<std::mutex> hold(g_temp_lock);
+    all.swap(g_temp_free);
+    g_temp_free_bytes = 0;
+  }
+  int current = 0;
+  (void)hipGetDevice(&current);
+  for (const TempBlock& b : all) {
+    if (b.device != current) (void)hipSetDevice(b.device);
+    (void)hipFree(b.ptr);
+    if (b.device != current) (void)hipSetDevice(current);
+  }
 }
 
 namespace {

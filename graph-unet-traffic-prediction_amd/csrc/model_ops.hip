@@ -39,7 +39,10 @@ struct gunet_plan {
   std::vector<Level> ups;      // depth; ups[l]: level l + 1 -> level l, over n_{l+1} + n_l nodes
   std::vector<int32_t*> parents;
   std::vector<char> one_parent_edge;   // ups[l] has exactly one edge per fine node (see build_plan)
-  std::vector<void*> owned;
+  std::vector<void*> owned;            // the chunks every array above is carved from
+  char* chunk = nullptr;               // free part of the newest chunk
+  size_t chunk_left = 0;
+  size_t chunk_bytes = 0;              // size of a fresh chunk (set from the level-0 graph)
 
   ~gunet_plan() {
     for (void* p : owned) (void)hipFree(p);
@@ -49,13 +52,22 @@ struct gunet_plan {
 namespace gunet {
 namespace {
 
+// The plan's arrays (some 150 of them for a depth-3 plan) are carved out of a few large chunks:
+// one hipMalloc per chunk instead of one per array.
 template <typename T>
 int plan_alloc(gunet_plan& P, T** out, int64_t count) {
-  void* p = nullptr;
-  const size_t bytes = sizeof(T) * static_cast<size_t>(count > 0 ? count : 1);
-  GUNET_HIP_TRY(hipMalloc(&p, bytes));
-  P.owned.push_back(p);
-  *out = static_cast<T*>(p);
+  const size_t bytes = (sizeof(T) * static_cast<size_t>(count > 0 ? count : 1) + 255) / 256 * 256;
+  if (bytes > P.chunk_left) {
+    const size_t fresh = bytes > P.chunk_bytes ? bytes : P.chunk_bytes;
+    void* p = nullptr;
+    GUNET_HIP_TRY(hipMalloc(&p, fresh));
+    P.owned.push_back(p);
+    P.chunk = static_cast<char*>(p);
+    P.chunk_left = fresh;
+  }
+  *out = reinterpret_cast<T*>(P.chunk);
+  P.chunk += bytes;
+  P.chunk_left -= bytes;
   return GUNET_OK;
 }
 
@@ -89,6 +101,13 @@ int finish_quadgraph(gunet_plan& P, gunet_plan::Level& L, hipStream_t stream) {
 int build_plan(gunet_plan& P, const int64_t* node_loc, int64_t n_nodes, const int32_t* const edge_index[4],
                const int64_t n_edges[4], hipStream_t stream) {
   const int D = P.depth;
+  {  // about what level 0 with its pooling and upsampling structures takes; coarser levels fit a second chunk
+    int64_t e_all = 0;
+    for (int q = 0; q < 4; ++q) e_all += n_edges[q];
+    const int64_t guess = 240 * n_nodes + 30 * e_all;
+    P.chunk_bytes = static_cast<size_t>(guess < (int64_t{256} << 10) ? (int64_t{256} << 10)
+                                                                     : (guess > (int64_t{64} << 20) ? (int64_t{64} << 20) : guess));
+  }
   P.levels.resize(D + 1);
   P.pools.resize(D);
   P.ups.resize(D);
@@ -418,6 +437,11 @@ int gunet_plan_destroy(gunet_plan* plan) {
 }
 
 int gunet_plan_depth(const gunet_plan* plan) { return plan ? plan->depth : GUNET_ERR_INVALID; }
+
+int gunet_release_temporaries(void) {
+  temp_cache_clear();
+  return GUNET_OK;
+}
 
 int gunet_plan_level(const gunet_plan* plan, int32_t level, gunet_quadgraph* graph_out, const int64_t** node_loc_out) {
   GUNET_REQUIRE(plan != nullptr, "plan_level: null plan");

@@ -385,6 +385,8 @@ def model_workspace_of(device):
 
 
 def release_workspaces():
-    """Drop every shared scratch buffer (they are re-allocated on demand)."""
+    """Drop every shared scratch buffer (they are re-allocated on demand) and the library's cache of
+    temporary blocks of the plan functions."""
     _workspaces.clear()
     _model_workspaces.clear()
+    call('gunet_release_temporaries')

@@ -258,6 +258,11 @@ int gunet_plan_create(const int64_t* node_loc, int64_t n_nodes, const int32_t* c
 int gunet_plan_destroy(gunet_plan* plan);
 int gunet_plan_depth(const gunet_plan* plan);
 
+/* The plan functions draw their temporary device memory from a cache inside the library (at most
+ * 256 MiB of idle blocks per process, reused stream by stream) instead of allocating and freeing
+ * per call; this frees every idle block of every device.  No counterpart in the reference. */
+int gunet_release_temporaries(void);
+
 /* Views into a plan (device pointers owned by the plan; any output may be NULL).
  *   level l in 0..depth:  the quadrant graph and node_loc int64 [n_nodes,2] after l poolings;
  *   pooling l in 0..depth-1: cluster int32 [n_l] (:423 new_node_ids) and, per quadrant, dup_map
