@@ -268,9 +268,12 @@ def source_stamp():
 
 def workload_key(args):
     """Key of the committed counter tables: only the default shape of each configuration has one."""
-    default_shape = (args.height, args.width, args.matmul, args.units) == (495, 436, 'f32', 32)
-    if not default_shape:
+    default_shape = (args.height, args.width, args.units) == (495, 436, 32)
+    if not default_shape or args.matmul not in ('f32', 'bf16'):
         return None
+    if args.matmul == 'bf16':
+        ok = args.config == 2 and (args.density, args.dense, args.min_units, args.batch) == (0.45, False, 128, 8)
+        return 'cfg2_bf16' if ok else None
     if args.config in (1, 2) and (args.density, args.dense, args.min_units) == (0.45, False, 128) and \
             args.batch == {1: 1, 2: 8}[args.config]:
         return f'cfg{args.config}'
@@ -341,6 +344,13 @@ def roofline_from_profile(prof, args, workload):
         roof['traffic'] = traffic['bytes_per_launch']
         roof['traffic_source'] = traffic['source']
         roof['traffic_stale'] = traffic['stale']
+        if dom == 'gemm_resident_bf16':
+            # K = 128..384 against 128 output columns in bf16 is 43..85 FLOP per byte, far left of the bf16
+            # ridge (312): these launches are priced by the bytes they move, not by the matrix peak
+            rate = traffic['bytes_per_launch'] / (ms / n * 1e-3) / 1e9
+            roof['measured_hbm_GBps'] = rate
+            roof['frac_of_hbm_peak'] = rate / workload.PEAK_HBM_GBPS
+            roof['note'] = 'memory-side kernel at bf16 operand widths: see measured_hbm_GBps; frac is against the dense bf16 matrix peak'
     return roof
 
 
@@ -604,13 +614,18 @@ def run_model(args, ranks):
     if work is not None:
         result['config'].update({'gflop_per_sample': work['total_flops'] / 1e9,
                                  'executed_gflop_per_sample': work['total_flops_executed'] / 1e9,
-                                 'compulsory_GB_per_sample': work['compulsory_bytes'] / 1e9})
+                                 'compulsory_GB_per_sample': work['compulsory_bytes'] / 1e9,
+                                 'staged_GB_per_sample': work['staged_bytes'] / 1e9})
         step_traffic = measured_step_traffic(args)
         if step_traffic is not None:
             # every feature kernel's measured HBM bytes per launch x its launches per forward, against the bytes a
             # fully fused layer would have to move (inputs read once, outputs written once)
+            # (compulsory), and against the same layers as the passes their data dependencies force: embeddings and
+            # messages through HBM once each (staged; gunet_amd/workload.py); both are float32 byte counts
             result['hbm_bytes_per_step_measured'] = step_traffic['bytes']
-            result['traffic_over_compulsory'] = step_traffic['bytes'] / (B * work['compulsory_bytes'])
+            if args.matmul == 'f32':
+                result['traffic_over_compulsory'] = step_traffic['bytes'] / (B * work['compulsory_bytes'])
+                result['traffic_over_staged'] = step_traffic['bytes'] / (B * work['staged_bytes'])
             result['hbm_bytes_per_step_stale'] = step_traffic['stale']
     if prof is not None:
         steps = args.steps

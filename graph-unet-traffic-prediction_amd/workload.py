@@ -9,7 +9,11 @@ edge-feature width F, global width G, U units (128 or 256), u = U / 4 (float32 =
   edge FLOPs      2*E*(F + 3u)*u   (as written; the kernel folds the u global columns into a bias)
   aggregate bytes 4*(E*u + E + N*U)   read messages + read slot->edge map + write aggregates
   gather bytes    4*(2*E*u + 2*E)     the two row gathers feeding the edge MLP
-  compulsory      4*(N*C + E*F + 2*E + E*u + N*U)
+  compulsory      4*(N*C + E*F + 2*E + E*u + N*U)   a layer as one pass: inputs read once, outputs written once
+  staged          4*(2*N*C + 3*N*U + E*F + 2*E + 2*E*u + 12*N)   the same layer as the three passes its
+                  data dependencies force (every message needs the embeddings of two arbitrary nodes, every
+                  node update all of its incoming messages): embeddings written and read once, x read by
+                  both GEMMs, messages written and read once, the in-edge table read once
 The "*_executed" totals count what the kernels issue after the algebraic savings (global columns
 folded into biases; the upsampling layer computed without its zero rows); roofline fractions of
 the MFMA kernels use these, so they can never exceed 1, and the as-written totals are reported
@@ -49,7 +53,7 @@ def layer_table(n_nodes, n_edges, f_e0=16, g0=113, in_features=104, out_units=96
 def work_per_sample(rows):
     """Totals for one sample: FLOPs per MFMA kernel class and bytes per HBM-bound class."""
     w = dict(gemm_flops=0.0, edge_flops=0.0, aggregate_bytes=0.0, gather_bytes=0.0, compulsory_bytes=0.0,
-             pool_bytes=0.0, gemm_launches=0, edge_launches=0, aggregate_launches=0,
+             pool_bytes=0.0, staged_bytes=0.0, gemm_launches=0, edge_launches=0, aggregate_launches=0,
              gemm_flops_executed=0.0, edge_flops_executed=0.0, aggregate_bytes_executed=0.0)
     for r in rows:
         U, SMALL_U = r['U'], r['U'] // 4
@@ -58,6 +62,7 @@ def work_per_sample(rows):
             w['gemm_flops_executed'] += 2.0 * r['n'] * r['k'] * r['out']
             w['gemm_launches'] += 1
             w['compulsory_bytes'] += 4.0 * r['n'] * (r['k'] + r['out'])
+            w['staged_bytes'] += 4.0 * r['n'] * (r['k'] + r['out'])
         elif r['kind'] == 'gn':
             n, e, c, f, g = r['n'], r['e'], r['c'], r['f'], r['g']
             w['gemm_flops'] += 2.0 * n * c * U + 2.0 * n * (c + U + g) * U
@@ -68,6 +73,13 @@ def work_per_sample(rows):
             w['aggregate_launches'] += 1
             w['gather_bytes'] += 4.0 * (2 * e * SMALL_U + 2 * e)
             w['compulsory_bytes'] += 4.0 * (n * c + e * f + 2 * e + e * SMALL_U + n * U)
+            if 'n_coarse' in r:
+                # embeddings of the coarse rows written and read, x read by the embedding and the column-sum
+                # GEMM, one message per fine row written and read, fine rows written
+                nc, nf = r['n_coarse'], r['n_fine']
+                w['staged_bytes'] += 4.0 * (2 * nc * c + 2 * nc * U + 2 * e * SMALL_U + 2 * e + nf * U)
+            else:
+                w['staged_bytes'] += 4.0 * (2 * n * c + 3 * n * U + e * f + 2 * e + 2 * e * SMALL_U + 12 * n)
             # what the kernels execute: the global columns are folded into biases, edge features
             # are padded to a multiple of 8, and the upsampling layer skips its zero rows
             if 'n_coarse' in r:
@@ -80,6 +92,7 @@ def work_per_sample(rows):
                 w['aggregate_bytes_executed'] += 4.0 * (e * SMALL_U + e + n * U)
         elif r['kind'] == 'pool':
             w['pool_bytes'] += 4.0 * (r['n'] * U + r['p'] * U) + 4.0 * (r['e'] * SMALL_U + r['e2'] * SMALL_U)
+            w['staged_bytes'] += 4.0 * (r['n'] * U + r['p'] * U) + 4.0 * (r['e'] * SMALL_U + r['e2'] * SMALL_U)
     w['total_flops'] = w['gemm_flops'] + w['edge_flops']
     w['total_flops_executed'] = w['gemm_flops_executed'] + w['edge_flops_executed']
     return w

@@ -8,7 +8,7 @@ passes were measured on (bench.py's source_stamp()); bench.py marks a table whos
 the sources it runs as stale.
 
 Kernel templates are merged into the classes bench.py's roofline speaks of (launch-weighted means):
-k_gemm_resident<NT, NKT, GATHER, BF16, RAGGED> -> 'k_gemm_resident<*, NKT>' for the float32
+k_gemm_resident<NT, NKT, GATHER, BF16, ...> -> 'k_gemm_resident<*, NKT>' for the float32
 instantiations and 'k_gemm_resident<.., bf16>' for the bf16 ones; every other kernel by its name
 without template arguments."""
 import csv
@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 def class_of(name):
     name = name.replace('gunet::', '')
-    m = re.match(r'k_gemm_resident<(\d+), (\d+), (\w+)(?:, (\w+))?(?:, (\w+))?>', name)
+    m = re.match(r'k_gemm_resident<(\d+), (\d+), (\w+)(?:, (\w+))?', name)
     if m:
         return 'k_gemm_resident<.., bf16>' if m.group(4) == 'true' else f'k_gemm_resident<*, {m.group(2)}>'
     return name.split('<')[0]
