@@ -121,12 +121,20 @@ int gunet_segment_sum_f32(const float* src, int64_t n_src, int32_t width, const 
                           float* out, gunet_stream_t stream);
 
 /* Arithmetic of every matrix product of the feature functions (Dense and the GN layer's node
- * embeddings, edge MLP and node MLP).  Storage is float32 in all modes; the accumulator is float32.
+ * embeddings, edge MLP and node MLP).  The accumulator is float32 in all modes, and so are all
+ * tensors at the interface (inputs, outputs, weights).
  *   GUNET_MATMUL_F32     v_mfma_f32_32x32x2_f32: exact float32 products (bitwise an fmaf chain).
  *   GUNET_MATMUL_SPLIT3  each operand = sum of 3 bf16 pieces, 6 piece products on the bf16 matrix
  *                        cores: float32-class accuracy (all dropped terms <= 2^-24 relative).
  *   GUNET_MATMUL_SPLIT2  2 pieces, 3 products: about 2^-17 relative per product.
- *   GUNET_MATMUL_BF16    operands rounded to bf16, 1 product: the bf16 tolerance class.
+ *   GUNET_MATMUL_BF16    operands rounded to bf16, 1 product: the bf16 tolerance class (2e-2 of the
+ *                        output's scale).  In this mode gunet_unet_forward_f32 / _static_f32 on a model
+ *                        whose blocks are all 128 wide, over a plan with at most 3 incoming edges per
+ *                        node and quadrant (every pixel-grid graph), also keeps its intermediates --
+ *                        node features, node embeddings, messages, pooled features -- in bf16 inside
+ *                        the workspace (each rounded once from the float32 result); edges_out and
+ *                        global_out are still float32.  Other models, and the per-layer functions, store
+ *                        float32.
  * The setting is process-wide and read at launch time.  No counterpart in the reference
  * (TensorFlow float32 matmuls). */
 #define GUNET_MATMUL_F32 0

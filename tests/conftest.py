@@ -52,12 +52,26 @@ def elementwise_err(got, want, floor=0.1):
 
 
 def assert_close(got, want, tol=1e-5, what=''):
-    """The two float32 parity gates: normwise max|d| / max|want| <= tol, and elementwise
+    """The float32 parity gates: normwise max|d| / max|want| <= tol; elementwise
     |d| <= tol * max(|want|, 0.1 max|want|) (every entry within a decade of the scale holds `tol`
-    relative to itself, smaller ones tol/10 of the scale absolutely)."""
-    n, e = rel_err(got, want), elementwise_err(got, want)
-    assert n <= tol and e <= tol, f'{what}: normwise {n:.2e}, elementwise {e:.2e} (gate {tol:.0e})'
+    relative to itself, smaller ones tol/10 of the scale absolutely); and, two decades down,
+    |d| <= 10 tol * max(|want|, 0.01 max|want|).  The last one is as far as two float32 evaluations
+    of the same dot products can be held to each other: with the floor at 0.01 the results here differ
+    from the float32 oracle by 1e-5 .. 8e-5 elementwise, which is the oracle's own distance from the
+    float64 value (assert_bracketed measures exactly that where a float64 run is affordable)."""
+    n, e, e2 = rel_err(got, want), elementwise_err(got, want), elementwise_err(got, want, 0.01)
+    assert n <= tol and e <= tol and e2 <= 10 * tol, \
+        f'{what}: normwise {n:.2e}, elementwise {e:.2e} (gate {tol:.0e}), at the 0.01 floor {e2:.2e} (gate {10 * tol:.0e})'
     return n, e
+
+
+def exact_inputs(x, graph, weights):
+    """float64 copies of a forward's inputs: the oracle run on them is the exact value the float32
+    results are bracketed against."""
+    w64 = {k: np.asarray(v, np.float64) for k, v in weights.items()}
+    g64 = {'edge_index': list(graph['edge_index']), 'edges': [np.asarray(e, np.float64) for e in graph['edges']],
+           'node_loc': graph['node_loc'], 'global': np.asarray(graph['global'], np.float64)}
+    return np.asarray(x, np.float64), g64, w64
 
 
 def assert_bracketed(got, want32, exact, tol=1e-5, what=''):

@@ -304,7 +304,8 @@ def test_graph_upsampling_layer(amd, oracle):
 @pytest.mark.parametrize('mode,tol', [('split3', 1e-5), ('bf16', 2e-2)])
 def test_matmul_modes(amd, oracle, mode, tol):
     """The bf16-matrix-core modes: 'split3' (three bf16 pieces per operand, six products) holds the
-    float32 gate of 1e-5, 'bf16' (one product) the bf16 gate of 2e-2; storage stays float32."""
+    float32 gate of 1e-5, 'bf16' (one product; on this checkpoint-shaped model the intermediates of the
+    whole-model call are kept in bf16 as well) the bf16 gate of 2e-2."""
     x, graph, _ = make_case(oracle, 40, 52, 0.45)
     W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
     want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)

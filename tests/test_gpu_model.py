@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, rel_err
+from conftest import assert_bracketed, assert_close, exact_inputs, rel_err
 from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -108,8 +108,13 @@ def test_unet_forward_one_call(amd, oracle, size, batch):
         want_y, want_g = oracle.graph_unet_forward(xs[b], copy_graph(graphs[b]), W)
         assert_close(got_y[b].cpu().numpy(), want_y, TOL)
         assert_close(got_g['global'][b:b + 1].cpu().numpy(), want_g['global'], TOL)
+        # no further from the float64 forward than twice the float32 oracle is
+        exact_y, exact_g = oracle.graph_unet_forward(*exact_inputs(xs[b], graphs[b], W))
+        assert_bracketed(got_y[b].cpu().numpy(), want_y, exact_y, TOL, f'sample {b}')
         for q in range(4):
             assert_close(got_g['edges'][q][b].cpu().numpy(), want_g['edges'][q], TOL)
+            assert_bracketed(got_g['edges'][q][b].cpu().numpy(), want_g['edges'][q], exact_g['edges'][q], TOL,
+                             f'sample {b}, messages of direction {q}')
             assert np.array_equal(got_g['edge_index'][q].cpu().numpy(), want_g['edge_index'][q])
     # the layer objects, one library call per layer: same kernels, same order
     model.native_forward = False
@@ -369,3 +374,29 @@ def test_plan_pool_features_and_predict_out(amd, oracle):
     assert got.data_ptr() == buf[2:4].data_ptr() and torch.equal(buf[2:4], want) and not buf[:2].any() and not buf[4:].any()
     with pytest.raises(ValueError):
         model.predict(xb, batch_graph(), out=buf[:3])
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_forward_repeats_bit_for_bit_over_a_poisoned_workspace(amd, oracle, mode):
+    """The same forward 60 times with the shared workspace overwritten in between: every run must
+    give the bits of the first.  Nothing in the workspace may be read before it is written, and no
+    kernel may depend on timing (this is the check that caught an LDS pick-up the compiler had split
+    into a 12-byte and two narrower reads, which now and then returned zeros in bf16 mode)."""
+    from gunet_amd import plan
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    x, graph, _ = make_case(oracle, 40, 52, 0.45)
+    g0 = graph_to_dev(graph)
+    xd = to_dev(x)
+    amd.set_matmul_mode(mode)
+    try:
+        first, _ = model(xd, dict(g0))
+        first = first.clone()
+        assert torch.isfinite(first).all()
+        for it in range(60):
+            for buf in plan._model_workspaces.values():
+                buf.fill_(0xFF)          # bytes 0xFF: NaN as float32 and as bf16
+            y, _ = model(xd, dict(g0))
+            assert torch.equal(y, first), f'run {it} differs from the first ({mode})'
+    finally:
+        amd.set_matmul_mode('f32')
