@@ -400,3 +400,86 @@ def test_forward_repeats_bit_for_bit_over_a_poisoned_workspace(amd, oracle, mode
             assert torch.equal(y, first), f'run {it} differs from the first ({mode})'
     finally:
         amd.set_matmul_mode('f32')
+
+
+def test_release_temporaries_frees_the_block_cache_and_plans_still_build(amd, oracle):
+    """The plan functions keep their temporary blocks in a cache inside the library;
+    gunet_release_temporaries() (plan.release_workspaces() calls it) hands them back, and the next
+    plan build -- from an empty cache -- gives the same index structures as one from a warm cache."""
+    from gunet_amd import plan
+    x, graph, _ = make_case(oracle, 97, 83, 0.4)
+    g = graph_to_dev(graph)
+    plan.clear_caches()
+    warm = plan.get_unet_plan(g['node_loc'], g['edge_index'], 3)
+    want = [[t.clone() for t in warm.level(l)['edge_index']] for l in range(4)]
+    want_cluster = [warm.pooling(l)[0].clone() for l in range(3)]
+    del warm
+    plan.clear_caches()
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    plan.release_workspaces()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= before          # idle blocks went back to the device
+    cold = plan.get_unet_plan(g['node_loc'], g['edge_index'], 3)
+    for l in range(4):
+        for q in range(4):
+            assert torch.equal(cold.level(l)['edge_index'][q], want[l][q])
+    for l in range(3):
+        assert torch.equal(cold.pooling(l)[0], want_cluster[l])
+
+
+@pytest.mark.parametrize('size', [(1, 2), (3, 5), (5, 4), (9, 33), (31, 17)])
+def test_bf16_mode_tiny_and_ragged_graphs(amd, oracle, size):
+    """bf16 mode (intermediates stored in bf16 inside the whole-model call) on graphs whose levels
+    run out of edges or nodes and whose row counts are no multiple of a 32-row group: 2e-2 against
+    the float32 oracle for the prediction, the global and the returned messages."""
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    model = _model(amd, W)
+    x, graph, _ = make_case(oracle, size[0], size[1], 1.0, dense=True)
+    want_y, want_g = oracle.graph_unet_forward(x, copy_graph(graph), W)
+    amd.set_matmul_mode('bf16')
+    try:
+        got_y, got_g = model(to_dev(x), graph_to_dev(graph))
+        assert rel_err(got_y.cpu().numpy(), want_y) <= 2e-2
+        assert rel_err(got_g['global'].cpu().numpy(), want_g['global']) <= 2e-2
+        for q in range(4):
+            assert got_g['edges'][q].dtype == torch.float32
+            if want_g['edges'][q].size:
+                assert rel_err(got_g['edges'][q].cpu().numpy(), want_g['edges'][q]) <= 2e-2, q
+    finally:
+        amd.set_matmul_mode('f32')
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_bf16_mode_random_shapes_and_batches(amd, oracle, seed):
+    rng = np.random.Generator(np.random.PCG64(1900 + seed))
+    h, w = int(rng.integers(5, 70)), int(rng.integers(5, 70))
+    density = float(rng.uniform(0.3, 0.9))
+    batch = int(rng.integers(1, 5))
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 20 + seed)
+    model = _model(amd, W)
+    x, graph, _ = make_case(oracle, h, w, density, graph_seed=seed)
+    node_loc, quads = graph['node_loc'], graph['edge_index']
+    enc = oracle.synth_street_encoding(node_loc.shape[0], 5)
+    xs, graphs = [], []
+    for b in range(batch):
+        sn, te, wd = oracle.synth_sample(node_loc, quads, 700 + 10 * seed + b, time_idx=b, weekday=b)
+        xb, gb = oracle.assemble_inputs(sn, enc, quads, node_loc, te, wd)
+        xs.append(xb)
+        graphs.append(gb)
+    g = graph_to_dev(graphs[0])
+    g['edges'] = [torch.stack([to_dev(gr['edges'][q]) for gr in graphs]) for q in range(4)]
+    g['global'] = torch.cat([to_dev(gr['global']) for gr in graphs], dim=0)
+    xd = torch.stack([to_dev(v) for v in xs])
+    amd.set_matmul_mode('bf16')
+    try:
+        got_y, got_g = model(xd, dict(g))
+        # a sample's result does not depend on the batch it is computed in, in this mode either
+        alone, _ = model(xd[:1].contiguous(), {**g, 'edges': [e[:1].contiguous() for e in g['edges']], 'global': g['global'][:1].contiguous()})
+        assert torch.equal(alone[0], got_y[0])
+    finally:
+        amd.set_matmul_mode('f32')
+    for b in range(batch):
+        want_y, want_g = oracle.graph_unet_forward(xs[b], copy_graph(graphs[b]), W)
+        assert rel_err(got_y[b].cpu().numpy(), want_y) <= 2e-2, (h, w, b)
+        assert rel_err(got_g['global'][b:b + 1].cpu().numpy(), want_g['global']) <= 2e-2
