@@ -69,6 +69,22 @@ def test_static_scratch_forward_matches_workspace_forward(oracle):
     assert sizes[1] < sizes[0]
 
 
+def test_static_scratch_forward_in_bf16_mode(oracle):
+    """The same pair of calls in bf16 mode, where the intermediates inside the scratch buffer are bf16
+    tensors: still bit-identical to the workspace form, outputs float32 and free of NaN."""
+    import gunet_amd as amd
+    W = oracle.make_weights(oracle.graph_unet_shapes(), 1)
+    amd.set_matmul_mode('bf16')
+    try:
+        for size, batch, seed in (((96, 90, 0.5), 2, 3), ((30, 26, 0.55), 1, 5)):
+            (want, got), _ = _forward_pair(amd, oracle, W, size, batch, seed)
+            for a, b in zip(want, got):
+                assert not np.isnan(b).any()
+                assert np.array_equal(a, b)
+    finally:
+        amd.set_matmul_mode('f32')
+
+
 def test_static_scratch_forward_allocates_nothing_and_runs_under_capture(oracle):
     """Device memory in use is the same before and after a call (hipMemGetInfo through torch), and
     the call can be recorded into a HIP graph right after its plan was made -- the plan's creation
