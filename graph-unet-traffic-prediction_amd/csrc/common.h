@@ -79,6 +79,24 @@ class DevBuf {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Activation codes (GUNET_ACT_*): linear and relu have tuned kernels; the others run on the generic ones.
+inline bool act_valid(int act) { return act >= GUNET_ACT_LINEAR && act <= GUNET_ACT_SWISH; }
+inline bool act_tuned(int act) { return act == GUNET_ACT_LINEAR || act == GUNET_ACT_RELU; }
+
+// Any activation by its code (the generic kernels; the tuned ones know linear and relu only).
+__device__ inline float activate_any(float v, int act) {
+  switch (act) {
+    case GUNET_ACT_RELU: return fmaxf(v, 0.0f);
+    case GUNET_ACT_TANH: return tanhf(v);
+    case GUNET_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case GUNET_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+    case GUNET_ACT_SOFTPLUS: return fmaxf(v, 0.0f) + log1pf(expf(-fabsf(v)));
+    case GUNET_ACT_SELU: return 1.0507009873554805f * (v > 0.0f ? v : 1.6732632423543772f * expm1f(v));
+    case GUNET_ACT_SWISH: return v / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
 // Kernel classes of the optional event profiler (gunet_profile_*).
 enum ProfClass {
   kProfGemmTiled = 0,

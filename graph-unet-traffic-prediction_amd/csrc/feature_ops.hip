@@ -443,6 +443,7 @@ struct EdgeArgs {
   const float* ebias;       // [B, 4, u]
   double* partial;          // [B, 4, gridDim.x, u] column sums of the messages
   int relu;
+  int act;                  // activation code (the tuned kernels take linear / relu; others go the generic way)
   int sender_only;          // receivers contribute through the bias (graph upsampling)
   float out_scale;          // stored message = out_scale * message (the column sums stay unscaled)
 };
@@ -1207,7 +1208,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_bridge(LayerPtrs pc, c
 // Per sample: gbias = global . W_node[c_in + U .., :] + b; the chained global transforms; ebias of
 // direction q = chain_q . W_edge_q[f_e + 2u .., :] + b (see k_layer_prologue).
 __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue_wide(LayerPtrs p, int U,
-                                                                       const float* __restrict__ global_in, int relu,
+                                                                       const float* __restrict__ global_in, int act,
                                                                        float* __restrict__ ebias,
                                                                        float* __restrict__ gbias) {
   extern __shared__ __attribute__((aligned(16))) float wsh[];
@@ -1232,7 +1233,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_layer_prologue_wide(LayerPtrs
       float s = 0.0f;
       for (int k = 0; k < kin; ++k) s = fmaf(src[k], p.glob_w[q][k * u + j], s);
       if (p.glob_b[q]) s += p.glob_b[q][j];
-      gq[q * u + j] = activate(s, relu);
+      gq[q * u + j] = activate_any(s, act);
     }
     __syncthreads();
   }
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update_wide(LayerPtrs 
                                                                       const float* __restrict__ global_in,
                                                                       const double* __restrict__ npart, int n_nblk,
                                                                       const double* __restrict__ epart, int n_eblk,
-                                                                      int relu, float* __restrict__ global_out) {
+                                                                      int act, float* __restrict__ global_out) {
   extern __shared__ __attribute__((aligned(16))) float wsh[];
   const int u = U / 4;
   float* gin = wsh;   // [g + U + u]
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_global_update_wide(LayerPtrs 
       float s = 0.0f;
       for (int k = 0; k < kin; ++k) s = fmaf(gin[k], p.globt_w[static_cast<int64_t>(k) * U + c], s);
       if (p.globt_b) s += p.globt_b[c];
-      global_out[b * U + c] = activate(s, relu);
+      global_out[b * U + c] = activate_any(s, act);
     }
   } else {
     for (int k = tid; k < kin; k += blockDim.x) global_out[b * kin + k] = gin[k];
@@ -1317,8 +1318,10 @@ struct EdgeSplit {
 };
 
 // Layers the tuned edge kernel does not serve: more than 64 columns per direction (its weights would
-// not fit LDS) or more than 64 edge features.
-inline bool edge_is_generic(const gunet_gn_weights* w) { return w->units > 256 || w->f_e > 64; }
+// not fit LDS), more than 64 edge features, or an activation other than linear / relu.
+inline bool edge_is_generic(const gunet_gn_weights* w, int act) {
+  return w->units > 256 || w->f_e > 64 || !act_tuned(act);
+}
 
 // Column-sum partial rows per sample the tiled GEMM writes for a problem of n_rows rows.
 inline int tiled_colsum_rows(int n_rows, int64_t batch) {
@@ -1331,10 +1334,10 @@ inline int tiled_colsum_rows(int n_rows, int64_t batch) {
   return gemm_colsum_rows(probe, 1, batch, nullptr);
 }
 
-EdgeSplit edge_split(const gunet_quadgraph* g, const gunet_gn_weights* w, int64_t batch) {
+EdgeSplit edge_split(const gunet_quadgraph* g, const gunet_gn_weights* w, int64_t batch, int act) {
   int max_e = 1;
   for (int q = 0; q < 4; ++q) max_e = g->n_edges[q] > max_e ? g->n_edges[q] : max_e;
-  if (edge_is_generic(w)) {   // one GEMM per direction; the reader adds the same number of rows of each
+  if (edge_is_generic(w, act)) {   // one GEMM per direction; the reader adds the same number of rows of each
     int rows = 1;
     for (int q = 0; q < 4; ++q) rows = std::max(rows, g->n_edges[q] > 0 ? tiled_colsum_rows(g->n_edges[q], batch) : 0);
     return {0, rows};
@@ -1391,8 +1394,7 @@ int check_layer_args(const char* fn, const gunet_quadgraph* graph, const gunet_g
                      int32_t activation, const void* workspace, size_t workspace_bytes, LayerWorkspace* ws) {
   GUNET_REQUIRE(graph && w, "%s: null graph or weights", fn);
   GUNET_REQUIRE(batch > 0, "%s: batch must be positive", fn);
-  GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU, "%s: unknown activation %d",
-                fn, activation);
+  GUNET_REQUIRE(act_valid(activation), "%s: unknown activation %d", fn, activation);
   if (w->units != 128 && w->units != 256 && w->units != 512 && w->units != 1024) {
     set_error("%s: units = %d is not implemented (128, 256, 512 and 1024 are)", fn, w->units);
     return GUNET_ERR_UNSUPPORTED;
@@ -1443,10 +1445,11 @@ LayerPtrs layer_ptrs(const gunet_gn_weights* w) {
   return p;
 }
 
+// `relu`: the layer's activation code; linear (0) and relu (1) on layers up to 256 wide take the tuned kernels
 int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu, int fold_receiver,
                     int32_t batch, const LayerWorkspace& ws, hipStream_t stream) {
   ProfScope prof(kProfPrologue, stream);
-  if (ut > 2) {
+  if (ut > 2 || !act_tuned(relu)) {
     GUNET_REQUIRE(!fold_receiver, "layer_prologue: the zero-row-free upsampling form is not implemented above 256 units");
     k_layer_prologue_wide<<<batch, kSmallThreads, sizeof(float) * (p.g + 128 * ut), stream>>>(p, 128 * ut, global_in, relu,
                                                                                             ws.ebias, ws.gbias);
@@ -1467,7 +1470,7 @@ int launch_prologue(const LayerPtrs& p, int ut, const float* global_in, int relu
 int launch_global_update(const LayerPtrs& p, int ut, const float* global_in, int n_nblk, int n_eblk, int relu,
                          int32_t batch, const LayerWorkspace& ws, float* global_out, hipStream_t stream) {
   ProfScope prof(kProfGlobalUpdate, stream);
-  if (ut > 2) {
+  if (ut > 2 || !act_tuned(relu)) {   // (`relu` is the activation code, as in launch_prologue)
     k_global_update_wide<<<batch, kSmallThreads, sizeof(float) * (p.g + 160 * ut), stream>>>(
         p, 128 * ut, global_in, ws.npart, n_nblk, ws.epart, n_eblk, relu, global_out);
     GUNET_LAUNCH_CHECK();
@@ -1578,6 +1581,7 @@ int launch_edge_generic(const EdgeArgs& a, const gunet_gn_weights* w, const gune
     for (int i = 0; i < s; ++i) g.seg[i].ldw = u;
     g.n_rows = graph->n_edges[q];
     g.relu = a.relu;
+    g.act = a.act;
     g.colsum_tiles = 4 * n_eblk;
     g.colsum_tile0 = q * n_eblk;
     GUNET_REQUIRE(gemm_colsum_rows([&] { GemmArgs t = g; double d; t.colsum = &d; return t; }(), 1, batch, nullptr) <= n_eblk,
@@ -1594,7 +1598,7 @@ int launch_edge_generic(const EdgeArgs& a, const gunet_gn_weights* w, const gune
 // pad_scratch: room for batch * max_q E_q * 4 floats (the layer's aggregate buffer, idle at this point)
 int launch_edge_mlp(EdgeArgs& a, int ut, const gunet_quadgraph* graph, const gunet_gn_weights* w,
                     const float* const edges[4], int32_t batch, void* wpack, float* pad_scratch, hipStream_t stream) {
-  const EdgeSplit split = edge_split(graph, w, batch);
+  const EdgeSplit split = edge_split(graph, w, batch, a.act);
   const int n_eblk = split.n_eblk;
   if (split.eg == 0) {
     double edges_total = 0.0;
@@ -1646,7 +1650,7 @@ int launch_edge_mlp16_inst(const Edge16Args& a, int eg, dim3 grid, hipStream_t s
 // [B, E_q, 16] / [E_q, 16] (f_e = 16, edges_f32), or null for the sender-only form.
 int launch_edge_mlp16(Edge16Args& a, const gunet_quadgraph* graph, const gunet_gn_weights* w, const void* const edges[4],
                       bool edges_f32, bool sender_only, int32_t batch, hipStream_t stream) {
-  const EdgeSplit split = edge_split(graph, w, batch);
+  const EdgeSplit split = edge_split(graph, w, batch, a.relu ? GUNET_ACT_RELU : GUNET_ACT_LINEAR);
   GUNET_REQUIRE(split.eg != 0 && w->units == 128, "edge_mlp16: a 128-wide layer is needed");
   double edges_total = 0.0;
   for (int q = 0; q < 4; ++q) {
@@ -1837,13 +1841,16 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
                 "gn_layer: x, x_skip and x_out must be 16-byte aligned");
   for (int q = 0; q < 4; ++q)
     GUNET_REQUIRE(graph->n_edges[q] == 0 || edges_out[q], "gn_layer: null edges_out[%d]", q);
-  const int relu = activation == GUNET_ACT_RELU;
+  // `relu` feeds the tuned kernels (linear / relu); any other activation takes the generic kernels
+  // throughout: wide per-sample kernels, tiled GEMMs, per-direction edge GEMMs, a separate aggregation
+  const int relu = activation == GUNET_ACT_RELU, act = activation;
+  GUNET_REQUIRE(!s16 || act_tuned(act), "gn_layer: bf16 storage serves linear and relu only");
   const int n = graph->n_nodes;
   const int U = w->units, u = U / 4, ut = U / 128;
   const int c_a = w->c_in - c_skip;          // width of x; x_skip supplies the remaining columns
   const LayerPtrs p = layer_ptrs(w);
 
-  if (!(flags & kGnSkipPrologue)) GUNET_TRY(launch_prologue(p, ut, global_in, relu, 0, batch, ws, stream));
+  if (!(flags & kGnSkipPrologue)) GUNET_TRY(launch_prologue(p, ut, global_in, act, 0, batch, ws, stream));
 
   {  // node embeddings of the four directions in one GEMM per 128 columns (hybrid_gnn.py:91-92)
     GemmArgs g = {};
@@ -1858,6 +1865,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     g.seg[1].ldw = u;
     g.n_rows = n;
     g.relu = relu;
+    g.act = act;
     g.a16 = g.o16 = s16;
     auto w_of = [&](int s, int col) {
       return w->node_emb_w[col / u] + (s == 0 ? 0 : static_cast<int64_t>(c_a) * u) + col % u;
@@ -1894,6 +1902,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     a.ebias = ws.ebias;
     a.partial = ws.epart;
     a.relu = relu;
+    a.act = act;
     a.out_scale = 1.0f;
     a.ef_shared = (flags & kGnEdgesShared) ? 1 : 0;
     GUNET_TRY(launch_edge_mlp(a, ut, graph, w, edges, batch, ws.wpack, ws.agg, stream));
@@ -1922,6 +1931,7 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
     for (int i = 0; i < s; ++i) g.seg[i].ldw = U;
     g.n_rows = n;
     g.relu = relu;
+    g.act = act;
     g.a16 = g.o16 = s16;
   }
   // With a per-node table of incoming edges the GEMM sums the messages while it loads them
@@ -1977,8 +1987,8 @@ int gn_layer_run(const gunet_quadgraph* graph, const gunet_gn_weights* w, int32_
 
   if (n_partials_out) *n_partials_out = n_partials;
   if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-  return launch_global_update(p, ut, global_in, n_partials, edge_split(graph, w, batch).n_eblk, relu, batch, ws, global_out,
-                              stream);
+  return launch_global_update(p, ut, global_in, n_partials, edge_split(graph, w, batch, act).n_eblk, act, batch, ws,
+                              global_out, stream);
 }
 
 int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_gn_weights* w, int32_t batch,
@@ -1998,9 +2008,10 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
                 static_cast<long long>(n_edges), n_fine);
   GUNET_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out) % 16 == 0,
                 "gn_upsample: x and x_out must be 16-byte aligned");
-  if (w->units > 256) {
-    set_error("gn_upsample: the zero-row-free form is implemented for 128 and 256 units; run the layer on [x ; 0] "
-              "(gunet_gn_layer_forward_f32 on the upsampling graph) for %d", w->units);
+  if (w->units > 256 || !act_tuned(activation)) {
+    set_error("gn_upsample: the zero-row-free form is implemented for 128 and 256 units with a linear or relu "
+              "activation; run the layer on [x ; 0] (gunet_gn_layer_forward_f32 on the upsampling graph) for %d units, "
+              "activation %d", w->units, activation);
     return GUNET_ERR_UNSUPPORTED;
   }
   const int relu = activation == GUNET_ACT_RELU;
@@ -2095,8 +2106,8 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
     }
     if (n_partials_out) *n_partials_out = tiles_total;
     if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-    return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, w, batch).n_eblk, relu, batch, ws, global_out,
-                                stream);
+    return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, w, batch, activation).n_eblk, relu, batch, ws,
+                                global_out, stream);
   }
 
   // messages: every edge goes (coarse parent -> fine node); edge features are zero.  Stored
@@ -2170,8 +2181,8 @@ int gn_upsample_run(const gunet_quadgraph* graph, int32_t n_coarse, const gunet_
   }
   if (n_partials_out) *n_partials_out = tiles_total;
   if (flags & kGnSkipGlobalUpdate) return GUNET_OK;
-  return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, w, batch).n_eblk, relu, batch, ws, global_out,
-                              stream);
+  return launch_global_update(p, ut, global_in, tiles_total, edge_split(graph, w, batch, activation).n_eblk, relu, batch, ws,
+                              global_out, stream);
 }
 
 int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int n_partials, const float* global_in,
@@ -2189,10 +2200,11 @@ int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int
   GUNET_REQUIRE(n_partials >= 0 && n_partials <= wc.n_nblk + 5, "gn_bridge: %d column-sum rows", n_partials);
   const LayerPtrs pc = layer_ptrs(cur), pn = layer_ptrs(next);
   const int utc = cur->units / 128, utn = next->units / 128;
-  if (utc > 2 || utn > 2) {   // a wide layer on either side: its own kernels, one after the other
-    const int relu_ = activation == GUNET_ACT_RELU;
-    GUNET_TRY(launch_global_update(pc, utc, global_in, n_partials, edge_split(cur_graph, cur, batch).n_eblk, relu_, batch,
-                                   wc, global_out, stream));
+  if (utc > 2 || utn > 2 || !act_tuned(activation)) {
+    // a wide layer on either side, or an activation beyond relu: the layers' own kernels, one after the other
+    const int relu_ = activation;
+    GUNET_TRY(launch_global_update(pc, utc, global_in, n_partials, edge_split(cur_graph, cur, batch, activation).n_eblk, relu_,
+                                   batch, wc, global_out, stream));
     const float* next_in = global_out;
     if (extra != nullptr) {
       k_concat_rows<<<batch, 256, 0, stream>>>(global_out, g_new, extra, extra_width, cat_out);
@@ -2205,7 +2217,7 @@ int gn_bridge(const gunet_quadgraph* cur_graph, const gunet_gn_weights* cur, int
   GUNET_REQUIRE(lds <= 64 * 1024, "gn_bridge: global vectors of %d and %d floats do not fit", pc.g, pn.g);
   const int relu = activation == GUNET_ACT_RELU;
   ProfScope prof(kProfBridge, stream);
-  const int n_eblk = edge_split(cur_graph, cur, batch).n_eblk;
+  const int n_eblk = edge_split(cur_graph, cur, batch, activation).n_eblk;
   return utc == 1 ? launch_bridge_utc<1>(pc, pn, utn, lds, batch, global_in, n_partials, n_eblk, wc, relu, global_out,
                                          extra, extra_width, cat_out, next_fold_receiver, wn, stream)
                   : launch_bridge_utc<2>(pc, pn, utn, lds, batch, global_in, n_partials, n_eblk, wc, relu, global_out,

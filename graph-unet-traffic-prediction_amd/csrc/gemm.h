@@ -51,6 +51,8 @@ struct GemmArgs {
                               //   fixed order and adds the group sums in float64, so the total does not
                               //   depend (beyond float64 rounding) on which kernel ran or how it split the rows.
   int relu;
+  int act;                    // activation code when it is neither linear nor relu (GUNET_ACT_TANH ..; `relu` is 0
+                              // then): only the tiled float32 kernel serves it
   // Gathered last segment (weights-resident kernel only): when gather_table is set, the last
   // segment (k = 128) is not read from seg[].a; row v's column block q is formed while loading as
   // gather_scale * (sum over j of row gather_table[(v * 4 + q) * 3 + j] (>= 0, in that order) of

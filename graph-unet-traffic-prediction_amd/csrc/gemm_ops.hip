@@ -38,7 +38,9 @@ __device__ inline float activate(float v, int relu) { return relu ? fmaxf(v, 0.0
 // keep the number of column-sum partial rows small) and writes partial row `wg`.  `ct` shifts the
 // launch's columns by 32 * ct: small launches are cut into NT = 1 column slices (grid z) so that
 // four times as many waves share the matrix work.
-template <int NT>
+// ANY_ACT = true: the activation is g.act, any of the GUNET_ACT_* codes (an instantiation of its own,
+// so that the transcendental functions cost the linear / relu form neither registers nor code).
+template <int NT, bool ANY_ACT = false>
 __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, const int tpw, const int ct) {
   constexpr int BN = 32 * NT;
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BN];
@@ -212,7 +214,7 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
           for (int r8 = 0; r8 < 8; ++r8) {
             const int r = 8 * h + r8;
             const int rl = (r & 3) + 8 * (r8 >> 2) + 4 * lh;
-            const float v = activate(acc[n][r] + bias_v[n], g.relu);
+            const float v = ANY_ACT ? activate_any(acc[n][r] + bias_v[n], g.act) : activate(acc[n][r] + bias_v[n], g.relu);
             stage[rl * 32 + li] = v;
             if (wrow0 + 16 * h + rl < g.n_rows) cs[n] += v;
           }
@@ -244,9 +246,9 @@ __device__ __forceinline__ void gemm_f32_tiles(const GemmArgs& g, const int wg, 
   }
 }
 
-template <int NT>
+template <int NT, bool ANY_ACT = false>
 __global__ __launch_bounds__(kThreads, 3) void k_gemm_f32(GemmArgs g, int tpw) {
-  gemm_f32_tiles<NT>(g, blockIdx.x, tpw, blockIdx.z);
+  gemm_f32_tiles<NT, ANY_ACT>(g, blockIdx.x, tpw, blockIdx.z);
 }
 
 // Up to four independent problems of the same column-tile count in one grid (the four quadrant
@@ -749,7 +751,7 @@ __global__ __launch_bounds__((GATHER && NT == 4) ? kResGatherThreads : kResThrea
 // Any shape, one thread per output element (used only when k or n_out break the tile rules).
 __global__ void k_dense_naive(const float* __restrict__ x, int64_t rows, int k,
                               const float* __restrict__ w, const float* __restrict__ bias, int n_out,
-                              int relu, float* __restrict__ out) {
+                              int act, float* __restrict__ out) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (idx >= rows * n_out) return;
   const int64_t r = idx / n_out;
@@ -757,7 +759,7 @@ __global__ void k_dense_naive(const float* __restrict__ x, int64_t rows, int k,
   float s = 0.0f;
   for (int j = 0; j < k; ++j) s = fmaf(x[r * k + j], w[static_cast<int64_t>(j) * n_out + c], s);
   if (bias) s += bias[c];
-  out[idx] = activate(s, relu);
+  out[idx] = activate_any(s, act);
 }
 
 // ---------------------------------------------------------------- GEMM on bf16 MFMA with split operands
@@ -1067,7 +1069,7 @@ inline int resident_block_waves(const GemmArgs& g, int nt) {
 }
 
 inline bool resident_ok(const GemmArgs& g, int nt, int64_t batch) {
-  if (g.row_map != nullptr || gathers_rows(g)) return false;
+  if (g.row_map != nullptr || gathers_rows(g) || g.act > GUNET_ACT_RELU) return false;
   if (g.a16 || g.o16) return true;   // bf16 storage: these kernels only (launch_gemm_resident16 knows the shapes)
   if (mode_pieces(g_matmul_mode) > 1) return false;   // split-bf16 modes: tiled kernel only
   const bool bf16 = bf16_mode();
@@ -1166,6 +1168,17 @@ inline bool tiled_offsets_fit(const GemmArgs& g) {
 
 int launch_tiled(int nt, bool group, dim3 grid, hipStream_t stream, const GemmArgs* g, int tpw, const GemmGroup* gg) {
   (void)group;
+  if (g != nullptr && g->act > GUNET_ACT_RELU) {   // an activation beyond relu: the instantiations that know them all
+    switch (nt) {
+      case 1: k_gemm_f32<1, true><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      case 2: k_gemm_f32<2, true><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      case 3: k_gemm_f32<3, true><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      case 4: k_gemm_f32<4, true><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
+      default: set_error("launch_gemm: bad column tile count %d", nt); return GUNET_ERR_INVALID;
+    }
+    GUNET_LAUNCH_CHECK();
+    return GUNET_OK;
+  }
   if (g != nullptr) {
     switch (nt) {
       case 1: k_gemm_f32<1><<<grid, kThreads, 0, stream>>>(*g, tpw); break;
@@ -1285,7 +1298,9 @@ int launch_gemm(GemmArgs g, int nt, int64_t batch, void* wpack, hipStream_t stre
       return GUNET_ERR_INVALID;
     }
   }
-  const bool resident = resident_ok(g, nt, batch), split = !resident && takes_split(wpack) && !gathers_rows(g);
+  // (an activation beyond relu takes the tiled float32 kernel in every matmul mode)
+  const bool resident = resident_ok(g, nt, batch),
+             split = !resident && takes_split(wpack) && !gathers_rows(g) && g.act <= GUNET_ACT_RELU;
   GUNET_REQUIRE(!g.paired || (resident && nt == 2), "launch_gemm: the paired form belongs to the weights-resident kernel");
   double flops = 0.0;
   for (int s = 0; s < g.n_seg; ++s) flops += 2.0 * batch * g.n_rows * g.seg[s].k * (32.0 * nt * (g.paired ? 2 : 1));
@@ -1337,7 +1352,8 @@ int launch_gemm_group(const GemmArgs* gs, int n, int nt, int64_t batch, void* wp
   for (int i = 0; i < n; ++i)
     if (gs[i].n_rows > 0) live[n_live++] = i;
   bool tiled = n_live > 1 && n_live <= kGemmGroup && batch > 0 && !takes_split(wpack);
-  for (int i = 0; i < n_live && tiled; ++i) tiled = !resident_ok(gs[live[i]], nt, batch);
+  for (int i = 0; i < n_live && tiled; ++i)   // (the grouped kernel knows linear and relu only)
+    tiled = !resident_ok(gs[live[i]], nt, batch) && gs[live[i]].act <= GUNET_ACT_RELU;
   if (!tiled) {
     for (int i = 0; i < n_live; ++i) GUNET_TRY(launch_gemm(gs[live[i]], nt, batch, wpack, stream));
     return GUNET_OK;
@@ -1398,8 +1414,8 @@ int dense_run(const float* x, int64_t rows, int32_t k, const float* kernel, cons
               int32_t activation, float* out, void* workspace, size_t workspace_bytes, int a16, int o16,
               hipStream_t stream) {
   GUNET_REQUIRE(rows >= 0 && k > 0 && n_out > 0, "dense_forward: bad shape");
-  GUNET_REQUIRE(activation == GUNET_ACT_LINEAR || activation == GUNET_ACT_RELU,
-                "dense_forward: unknown activation %d", activation);
+  GUNET_REQUIRE(act_valid(activation), "dense_forward: unknown activation %d", activation);
+  GUNET_REQUIRE(act_tuned(activation) || !(a16 || o16), "dense_forward: bf16 storage serves linear and relu only");
   if (rows == 0) return GUNET_OK;
   GUNET_REQUIRE(x && kernel && out, "dense_forward: null pointer");
   GUNET_REQUIRE(rows < INT32_MAX, "dense_forward: too many rows");
@@ -1409,8 +1425,7 @@ int dense_run(const float* x, int64_t rows, int32_t k, const float* kernel, cons
   if (!tiled) {
     const unsigned grid = static_cast<unsigned>(ceil_div(rows * n_out, kThreads));
     ProfScope prof(kProfDenseNaive, stream);
-    k_dense_naive<<<grid, kThreads, 0, stream>>>(x, rows, k, kernel, bias, n_out,
-                                                 activation == GUNET_ACT_RELU, out);
+    k_dense_naive<<<grid, kThreads, 0, stream>>>(x, rows, k, kernel, bias, n_out, activation, out);
     GUNET_LAUNCH_CHECK();
     return GUNET_OK;
   }
@@ -1439,6 +1454,7 @@ int dense_run(const float* x, int64_t rows, int32_t k, const float* kernel, cons
     g.ldo = n_out;
     g.out_col0 = col0;
     g.relu = activation == GUNET_ACT_RELU;
+    g.act = activation;
     g.a16 = a16;
     g.o16 = o16;
     GUNET_TRY(launch_gemm(g, nt, 1, workspace, stream));

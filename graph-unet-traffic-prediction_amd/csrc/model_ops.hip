@@ -573,6 +573,13 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
   GUNET_REQUIRE(P && w, "unet_forward: null plan or weights");
   GUNET_REQUIRE(batch > 0, "unet_forward: batch %d", batch);
   GUNET_REQUIRE(x && edges && global_in && out, "unet_forward: null tensor");
+  GUNET_REQUIRE(act_valid(activation) && act_valid(out_activation), "unet_forward: unknown activation %d / %d", activation,
+                out_activation);
+  if (!act_tuned(activation)) {
+    set_error("unet_forward: the one-call forward serves linear and relu layers; run activation %d layer by layer "
+              "(gunet_gn_layer_forward_f32 and the plan views)", activation);
+    return GUNET_ERR_UNSUPPORTED;
+  }
   GUNET_REQUIRE(workspace != nullptr && reinterpret_cast<uintptr_t>(workspace) % 256 == 0,
                 "unet_forward: the workspace must be 256-byte aligned");
   int dev = 0;
@@ -591,7 +598,7 @@ int unet_forward(const gunet_plan* P, const gunet_unet_weights* w, int32_t batch
   auto next_global = [&]() { return mb.globals + mb.global_slot * slot++; };
   // GUNET_MATMUL_BF16 on the shipped shapes: every intermediate tensor (node features, node
   // embeddings, messages; skip tensors included) is kept in bf16 in the first half of its buffer
-  const bool s16 = bf16_storage_ok(P, w, batch);
+  const bool s16 = bf16_storage_ok(P, w, batch) && act_tuned(out_activation);
   const int f16 = s16 ? kGnStore16 : 0;
   const int in32 = s16 ? kGnEdgesIn32 : 0;   // layers that read the caller's float32 edge features
 

@@ -23,12 +23,17 @@ from .._lib import GnWeightsStruct, call, current_stream, ptr, ptr4
 
 DEBUGGING = False
 
-_ACTIVATIONS = {None: _lib.ACT_LINEAR, 'linear': _lib.ACT_LINEAR, 'relu': _lib.ACT_RELU}
+# Keras activation names (the reference passes them to tf.keras.layers.Dense, hybrid_gnn.py:25).  relu
+# and linear run on the tuned kernels; the others on the library's generic ones, layer by layer.
+_ACTIVATIONS = {None: _lib.ACT_LINEAR, 'linear': _lib.ACT_LINEAR, 'relu': _lib.ACT_RELU, 'tanh': _lib.ACT_TANH,
+                'sigmoid': _lib.ACT_SIGMOID, 'elu': _lib.ACT_ELU, 'softplus': _lib.ACT_SOFTPLUS,
+                'selu': _lib.ACT_SELU, 'swish': _lib.ACT_SWISH}
+_TUNED = (_lib.ACT_LINEAR, _lib.ACT_RELU)
 
 
 def _activation_code(name):
     if name not in _ACTIVATIONS:
-        raise NotImplementedError(f'Activation "{name}" is not implemented (relu, linear, None).')
+        raise NotImplementedError(f'Activation "{name}" is not implemented ({", ".join(str(k) for k in _ACTIVATIONS)}).')
     return _ACTIVATIONS[name]
 
 
@@ -421,7 +426,7 @@ class GraphUpsampling2x2:
         glob = torch.cat((graph['global'].reshape(-1, graph['global'].shape[-1]),
                           target_graph['global'].reshape(-1, target_graph['global'].shape[-1])),
                          dim=-1)                                            # :375
-        if (isinstance(self.gcn, GeoQuadrantGCN) and self.gcn.units <= 256
+        if (isinstance(self.gcn, GeoQuadrantGCN) and self.gcn.units <= 256 and self.gcn._act in _TUNED
                 and sum(int(e.shape[0]) for e in up.edge_index) == up.n_fine):
             # same result as the layer on [x ; zeros] with zero edge features (:342-377), without
             # computing the zero rows

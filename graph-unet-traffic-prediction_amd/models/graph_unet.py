@@ -109,7 +109,8 @@ class GraphUNet(GraphBaseModel):
         gcns = [g for _, g in self._gn_layers()]
         blocks = self.downsampling_layers + self.upsampling_layers
         return (self.native_forward and 1 <= self.depth <= _lib.MAX_DEPTH
-                and all(type(g) is GeoQuadrantGCN and g.use_global for g in gcns)
+                and all(type(g) is GeoQuadrantGCN and g.use_global and g._act in (_lib.ACT_LINEAR, _lib.ACT_RELU)
+                        for g in gcns)
                 and all(not b.residual for b in blocks)
                 and all(b.n_layers == 1 for b in self.downsampling_layers)
                 and all(b.n_layers == 2 and b.upsampling.method == 'graph' and b.upsampling.col_idx == 0

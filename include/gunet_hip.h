@@ -36,8 +36,21 @@ extern "C" {
 #define GUNET_ERR_WORKSPACE (-3)   /* workspace too small */
 #define GUNET_ERR_UNSUPPORTED (-4) /* configuration the library does not implement */
 
+/* Activations (layers/hybrid_gnn.py:25, models/graph_unet.py:21 take any Keras activation name).
+ * LINEAR and RELU -- the shipped configuration -- run on the tuned kernels; the others give the same
+ * layer through the library's generic kernels (tiled float32 GEMMs, per-direction edge GEMMs, a separate
+ * aggregation pass; exact float32 in every matmul mode).  The whole-model entry points and the
+ * zero-row-free upsampling layer serve LINEAR / RELU only (GUNET_ERR_UNSUPPORTED otherwise: run the
+ * layers one by one).  Keras definitions: elu with alpha = 1, selu with its two constants, softplus =
+ * log(exp(x) + 1), swish = x * sigmoid(x). */
 #define GUNET_ACT_LINEAR 0
 #define GUNET_ACT_RELU 1
+#define GUNET_ACT_TANH 2
+#define GUNET_ACT_SIGMOID 3
+#define GUNET_ACT_ELU 4
+#define GUNET_ACT_SOFTPLUS 5
+#define GUNET_ACT_SELU 6
+#define GUNET_ACT_SWISH 7
 
 typedef void* gunet_stream_t;
 

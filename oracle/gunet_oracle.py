@@ -115,7 +115,29 @@ def identity(x):
     return x
 
 
-ACTIVATIONS = {'relu': relu, None: identity, 'linear': identity}
+def _f32_like(x, y):
+    return y.astype(x.dtype, copy=False)
+
+
+def sigmoid(x):
+    return _f32_like(x, 1 / (1 + np.exp(-x)))
+
+
+def softplus(x):                      # tf.keras.activations.softplus: log(exp(x) + 1)
+    return _f32_like(x, np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x))))
+
+
+def elu(x):                           # alpha = 1
+    return _f32_like(x, np.where(x > 0, x, np.expm1(np.minimum(x, 0))))
+
+
+def selu(x):                          # tf.keras.activations.selu: scale * elu(x, alpha)
+    return _f32_like(x, 1.0507009873554805 * np.where(x > 0, x, 1.6732632423543772 * np.expm1(np.minimum(x, 0))))
+
+
+# layers/hybrid_gnn.py:25 and models/graph_unet.py:21 pass the name to tf.keras.layers.Dense
+ACTIVATIONS = {'relu': relu, None: identity, 'linear': identity, 'tanh': np.tanh, 'sigmoid': sigmoid,
+               'elu': elu, 'softplus': softplus, 'selu': selu, 'swish': lambda x: _f32_like(x, x * sigmoid(x))}
 
 
 def column_sum(x):
