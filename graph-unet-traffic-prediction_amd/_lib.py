@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('GUNET_HIP_LIBRARY') or os.path.join(_HERE, 'libgunet_
 ACT_LINEAR = 0
 ACT_RELU = 1
 ACT_TANH, ACT_SIGMOID, ACT_ELU, ACT_SOFTPLUS, ACT_SELU, ACT_SWISH = 2, 3, 4, 5, 6, 7
+ACT_GELU, ACT_SOFTSIGN, ACT_EXPONENTIAL, ACT_HARD_SIGMOID = 8, 9, 10, 11
 
 MATMUL_MODES = {'f32': 0, 'split3': 1, 'split2': 2, 'bf16': 3}
 

@@ -80,7 +80,7 @@ class DevBuf {
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Activation codes (GUNET_ACT_*): linear and relu have tuned kernels; the others run on the generic ones.
-inline bool act_valid(int act) { return act >= GUNET_ACT_LINEAR && act <= GUNET_ACT_SWISH; }
+inline bool act_valid(int act) { return act >= GUNET_ACT_LINEAR && act <= GUNET_ACT_HARD_SIGMOID; }
 inline bool act_tuned(int act) { return act == GUNET_ACT_LINEAR || act == GUNET_ACT_RELU; }
 
 // Any activation by its code (the generic kernels; the tuned ones know linear and relu only).
@@ -93,6 +93,10 @@ __device__ inline float activate_any(float v, int act) {
     case GUNET_ACT_SOFTPLUS: return fmaxf(v, 0.0f) + log1pf(expf(-fabsf(v)));
     case GUNET_ACT_SELU: return 1.0507009873554805f * (v > 0.0f ? v : 1.6732632423543772f * expm1f(v));
     case GUNET_ACT_SWISH: return v / (1.0f + expf(-v));
+    case GUNET_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case GUNET_ACT_SOFTSIGN: return v / (1.0f + fabsf(v));
+    case GUNET_ACT_EXPONENTIAL: return expf(v);
+    case GUNET_ACT_HARD_SIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.0f), 1.0f);
     default: return v;
   }
 }

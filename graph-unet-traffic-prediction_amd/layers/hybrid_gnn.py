@@ -27,7 +27,8 @@ DEBUGGING = False
 # and linear run on the tuned kernels; the others on the library's generic ones, layer by layer.
 _ACTIVATIONS = {None: _lib.ACT_LINEAR, 'linear': _lib.ACT_LINEAR, 'relu': _lib.ACT_RELU, 'tanh': _lib.ACT_TANH,
                 'sigmoid': _lib.ACT_SIGMOID, 'elu': _lib.ACT_ELU, 'softplus': _lib.ACT_SOFTPLUS,
-                'selu': _lib.ACT_SELU, 'swish': _lib.ACT_SWISH}
+                'selu': _lib.ACT_SELU, 'swish': _lib.ACT_SWISH, 'gelu': _lib.ACT_GELU, 'softsign': _lib.ACT_SOFTSIGN,
+                'exponential': _lib.ACT_EXPONENTIAL, 'hard_sigmoid': _lib.ACT_HARD_SIGMOID}
 _TUNED = (_lib.ACT_LINEAR, _lib.ACT_RELU)
 
 

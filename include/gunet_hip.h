@@ -51,6 +51,10 @@ extern "C" {
 #define GUNET_ACT_SOFTPLUS 5
 #define GUNET_ACT_SELU 6
 #define GUNET_ACT_SWISH 7
+#define GUNET_ACT_GELU 8          /* exact form: 0.5 x (1 + erf(x / sqrt 2)) */
+#define GUNET_ACT_SOFTSIGN 9
+#define GUNET_ACT_EXPONENTIAL 10
+#define GUNET_ACT_HARD_SIGMOID 11 /* clip(0.2 x + 0.5, 0, 1) */
 
 typedef void* gunet_stream_t;
 

@@ -115,6 +115,11 @@ def identity(x):
     return x
 
 
+def _erf(x):
+    from scipy.special import erf
+    return erf(x)
+
+
 def _f32_like(x, y):
     return y.astype(x.dtype, copy=False)
 
@@ -137,7 +142,11 @@ def selu(x):                          # tf.keras.activations.selu: scale * elu(x
 
 # layers/hybrid_gnn.py:25 and models/graph_unet.py:21 pass the name to tf.keras.layers.Dense
 ACTIVATIONS = {'relu': relu, None: identity, 'linear': identity, 'tanh': np.tanh, 'sigmoid': sigmoid,
-               'elu': elu, 'softplus': softplus, 'selu': selu, 'swish': lambda x: _f32_like(x, x * sigmoid(x))}
+               'elu': elu, 'softplus': softplus, 'selu': selu, 'swish': lambda x: _f32_like(x, x * sigmoid(x)),
+               'gelu': lambda x: _f32_like(x, 0.5 * x * (1 + _erf(x / np.sqrt(2.0)))),       # approximate=False
+               'softsign': lambda x: _f32_like(x, x / (1 + np.abs(x))),
+               'exponential': lambda x: _f32_like(x, np.exp(x)),
+               'hard_sigmoid': lambda x: _f32_like(x, np.clip(0.2 * x + 0.5, 0, 1))}
 
 
 def column_sum(x):

@@ -10,7 +10,7 @@ from gpu_helpers import copy_graph, graph_to_dev, make_case, to_dev
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-NAMES = ['tanh', 'sigmoid', 'elu', 'softplus', 'selu', 'swish']
+NAMES = ['tanh', 'sigmoid', 'elu', 'softplus', 'selu', 'swish', 'gelu', 'softsign', 'exponential', 'hard_sigmoid']
 
 
 @pytest.fixture
@@ -38,7 +38,8 @@ def test_dense_activations(amd, oracle, name):
         assert_close(got, want, TOL, f'{name} {(rows, k, n)}')
 
 
-@pytest.mark.parametrize('name', NAMES)
+# ('exponential' is left to the Dense test: on this layer's weights exp overflows float32 in the oracle too)
+@pytest.mark.parametrize('name', [n for n in NAMES if n != 'exponential'])
 def test_gn_layer_activations(amd, oracle, name):
     c_in, f_e, g = 128, 16, 113
     node_loc, ei, d, _ = oracle.synth_road_graph(23, 31, 0.55, 2)
