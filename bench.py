@@ -611,7 +611,7 @@ def run_model(args, ranks):
         'plan': 'cached', 'plan_build_ms': plan_ms[1], 'plan_build_ms_very_first': plan_ms[0],
         'first_forward_ms': first_call_ms, 'quadrant_partition_ms': partition_ms,
         # the reference redoes the index work inside every forward: the same step with the plan built each time
-        'samples_per_s_with_plan_build_every_step': B / ((elapsed / args.steps) + plan_ms[1] * 1e-3),
+        'samples_per_s_with_plan_build_every_step': world * B / ((elapsed / args.steps) + plan_ms[1] * 1e-3),
     }
     if work is not None:
         result['config'].update({'gflop_per_sample': work['total_flops'] / 1e9,
