@@ -109,7 +109,10 @@ def test_cfg2_full_model_batch8_bf16_mode(amd, oracle):
     xb = to_dev(np.stack([s[0] for s in samples]))
     amd.set_matmul_mode('bf16')
     try:
-        y = model.predict(xb, g).cpu().numpy()
+        first = model.predict(xb, dict(g)).clone()     # (the graph dict is updated in place: a copy per call)
+        for _ in range(12):                            # full size, every launch filling the chip: same bits every time
+            assert torch.equal(model.predict(xb, dict(g)), first)
+        y = first.cpu().numpy()
     finally:
         amd.set_matmul_mode('f32')
     assert y.shape == (8, n, 96) and np.isfinite(y).all() and (y >= 0).all()
