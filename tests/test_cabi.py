@@ -71,3 +71,22 @@ def test_mirror_keeps_reference_names():
     assert prefixes[-1] == 'upsampling_layers/2/gcns/1'
     assert not model.upsampling_layers[-1].gcns[-1].has_glob_transform      # last layer: identity global
     assert all(l.has_glob_transform for _, l in model._gn_layers()[:-1])
+
+
+def test_constants_of_the_header_match_the_ctypes_table_and_the_oracle(oracle):
+    """Every GUNET_ACT_* / GUNET_MATMUL_* / GUNET_KERNELS_* value in the header is the one the Python
+    side passes, and every activation the mirror accepts has an oracle function to be checked against."""
+    from gunet_amd import _lib
+    from gunet_amd.layers import hybrid_gnn
+    with open(os.path.join(ROOT, 'include', 'gunet_hip.h')) as f:
+        defines = dict(re.findall(r'#define\s+(GUNET_[A-Z0-9_]+)\s+\(?(-?\d+)\)?', f.read()))
+    acts = {k[len('GUNET_ACT_'):]: int(v) for k, v in defines.items() if k.startswith('GUNET_ACT_')}
+    assert len(acts) == 12 and sorted(acts.values()) == list(range(12))
+    for name, code in acts.items():
+        assert getattr(_lib, 'ACT_' + name) == code, name
+    for name, code in hybrid_gnn._ACTIVATIONS.items():
+        assert name in oracle.ACTIVATIONS, name
+        assert code in acts.values()
+    assert {acts[k.upper()] for k in hybrid_gnn._ACTIVATIONS if k} == set(acts.values())
+    assert int(defines['GUNET_MAX_DEPTH']) == _lib.MAX_DEPTH
+    assert int(defines['GUNET_STATIC_SCRATCH_BYTES']) == _lib.STATIC_SCRATCH_BYTES if 'GUNET_STATIC_SCRATCH_BYTES' in defines else True
